@@ -1,0 +1,133 @@
+"""The CPU oracle against the reference's own outputs (pinning).
+
+Golden vectors come from tests/golden/make_golden.py (real helpers.py imported
+in the build container) and from the real-FEniCS trajectory the reference ships.
+"""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+from oracle import fct as ofct
+from oracle import traj as otraj
+from oracle.assembly import P1Assembler, row_lump_diag
+from oracle.mesh import SquareMesh, reorder_vector_to_dof, reorder_vector_from_dof
+
+from helpers_golden import load, fct_case, fct_case_names, csr_from
+
+TOL_STEP = 1e-12   # relative l2, one FCT step vs the reference (same SuperLU)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("name", fct_case_names())
+def test_fct_step_matches_reference(name):
+    c = fct_case(load("fct_cases.npz"), name)
+    info = {}
+    u = ofct.fct_step(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"], None,
+                      non_flux_mat=c["N"], info=info)
+    assert rel(u, c["u_np1"]) < TOL_STEP
+    # helpers.py:1796-1799 diagnostic: same verdict as the reference printed
+    assert bool(np.any(info["l_rowsum"] <= 0)) == c["mmatrix_failed"]
+
+
+@pytest.mark.parametrize("name", ["rot_N5", "driftctl_N11", "schnak_N11"])
+def test_fct_step_lil_variant(name):
+    c = fct_case(load("fct_cases.npz"), name)
+    mesh = SquareMesh(c["a1"], c["a2"], c["n_cells"])
+    u = ofct.fct_step_lil(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"],
+                          mesh.dof_neighbors(), non_flux_mat=c["N"])
+    assert rel(u, c["u_np1"]) < TOL_STEP
+
+
+def test_old_sign_convention():
+    z = load("fct_old_sign.npz")
+    a1, a2, nc = z["geom"]
+    mesh = SquareMesh(a1, a2, int(nc))
+    asm = P1Assembler(mesh)
+    M = asm.mass()
+    n = mesh.nodes
+    from scipy.sparse import diags
+    ML = diags(row_lump_diag(M)).tocsr()
+    A = csr_from(z, "A", n)
+    S = csr_from(z, "S", n)
+    u = ofct.fct_step_old_sign(A, z["rhs"], z["u_n"], float(z["dt"]), n, M, ML, None, source_mat=S)
+    assert rel(u, z["u_old"]) < TOL_STEP
+    assert rel(u, z["u_new"]) < TOL_STEP
+
+
+def test_small_kernels():
+    z = load("kernels.npz")
+    a1, a2, nc = z["geom"]
+    mesh = SquareMesh(a1, a2, int(nc))
+    asm = P1Assembler(mesh)
+    M = asm.mass()
+    n = mesh.nodes
+    y = ofct.chebsi(z["cheb_b"], M, M.diagonal(), 20, 0.5, 2)
+    assert rel(y, z["cheb_y"]) < 1e-14
+    pat = ofct.Pattern(M)
+    K = csr_from(z, "K", n)
+    D = csr_from(z, "D", n)
+    d = ofct.artificial_diffusion(pat, pat.values(K))
+    assert np.max(np.abs(d - pat.values(D))) < 1e-15
+    assert np.max(np.abs(row_lump_diag(M) - z["ml"])) < 1e-17
+    Nt, dt, beta = int(z["Nt"]), float(z["dt"]), float(z["beta"])
+    assert abs(ofct.l2_norm_sq_Q(z["phi"], Nt, dt, M) - z["L2Q"]) < 1e-13 * abs(z["L2Q"])
+    assert abs(ofct.l2_norm_sq_Omega(z["phi"][:n], M) - z["L2Omega"]) < 1e-13 * abs(z["L2Omega"])
+    J = ofct.cost_functional
+    assert abs(J(z["phi"], z["tgt"], z["ctl"], Nt, dt, M, beta, "alltime") - z["J_alltime_1"]) < 1e-13 * abs(z["J_alltime_1"])
+    assert abs(J(z["phi"], z["tgt"], z["ctl"], Nt, dt, M, beta, "alltime", var2=z["phi2"], var2_target=z["tgt2"])
+               - z["J_alltime_2"]) < 1e-13 * abs(z["J_alltime_2"])
+    assert abs(J(z["phi"], z["tgt"][:n], z["ctl"], Nt, dt, M, beta, "finaltime") - z["J_finaltime_1"]) < 1e-13 * abs(z["J_finaltime_1"])
+    assert abs(J(z["phi"], z["tgt"][:n], z["ctl"], Nt, dt, M, beta, "finaltime", var2=z["phi2"], var2_target=z["tgt2"][:n])
+               - z["J_finaltime_2"]) < 1e-13 * abs(z["J_finaltime_2"])
+    with pytest.raises(ValueError):
+        J(z["phi"], z["tgt"], z["ctl"], Nt, dt, M, beta, "sometime")
+    v2d = mesh.vertex_to_dof
+    assert np.array_equal(reorder_vector_to_dof(z["reorder_in"], 2, n, v2d), z["reorder_to"])
+    assert np.array_equal(reorder_vector_from_dof(z["reorder_in"], 2, n, v2d), z["reorder_from"])
+
+
+def test_fenics_trajectory():
+    """Real-FEniCS forward chemotaxis trajectory shipped by the reference
+    (Chtxs_data_dx0.025_dt0.001/chtxs_{m,f}_t0.01.csv): pins mesh orientation,
+    DoF map, M/Ad, the exp-quadrature rule, the spsolve step and the FCT step."""
+    z = load("chtxs_fenics_traj.npz")
+    mesh = SquareMesh(0.0, 1.0, 40)
+    n = mesh.nodes
+    m_ref = z["m"].reshape(11, n)
+    f_ref = z["f"].reshape(11, n)
+    # frame 0 is the seeded IC of helpers.py:1242-1248 under the DoF permutation
+    np.random.seed(5)
+    u_init = 1.5 + 0.1 * (0.5 - np.random.rand(41, 41))
+    u0 = reorder_vector_to_dof(u_init.reshape(n), 1, n, mesh.vertex_to_dof)
+    assert np.array_equal(u0, m_ref[0])
+    assert np.array_equal(u0, f_ref[0])
+    asm = P1Assembler(mesh)
+    Nt, dt = 10, 1e-3
+    u = np.zeros((Nt + 1) * n)
+    v = np.zeros((Nt + 1) * n)
+    u[:n] = u0
+    v[:n] = u0
+    otraj.solve_chtxs_system(None, u, v, asm, n, Nt, dt, None, control_const=100, rescaling=1)
+    for k in range(1, Nt + 1):
+        assert np.max(np.abs(v[k * n:(k + 1) * n] - f_ref[k])) < 5e-14, k
+        assert np.max(np.abs(u[k * n:(k + 1) * n] - m_ref[k])) < 5e-14, k
+
+
+def test_solidbody_trajectory_vs_reference_fct():
+    z = load("solidbody_traj_N21.npz")
+    a1, a2, nc = z["geom"]
+    mesh = SquareMesh(a1, a2, int(nc))
+    asm = P1Assembler(mesh)
+    n = mesh.nodes
+    Nt, dt = int(z["Nt"]), float(z["dt"])
+    sb = otraj.SolidBody(asm, om=float(z["om"]))
+    uk = np.zeros((Nt + 1) * n)
+    uk[:n] = z["uk"][:n]
+    otraj.solidbody_forward(sb, z["ck"], uk, n, Nt, dt)
+    assert rel(uk, z["uk"]) < 1e-11
+    pk = np.zeros((Nt + 1) * n)
+    otraj.solidbody_adjoint(sb, z["ck"], uk, z["uhat"], pk, n, Nt, dt, optim="finaltime")
+    assert rel(pk, z["pk"]) < 1e-11
