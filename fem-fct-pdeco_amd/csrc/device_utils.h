@@ -1,0 +1,96 @@
+// Device-side helpers shared by the gfx950 kernels: row partitioning (XCD-aware),
+// wave64/block reductions, level-indirected vector references.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+// A vector that may live inside a time-major trajectory whose current level is
+// held in a device-side counter (so that one captured hipGraph serves every
+// time step): address = base + (*level + level_off) * stride.
+struct VecRef {
+    const double* base;
+    const int32_t* level;   // may be null (level = 0)
+    int64_t stride;
+    int32_t level_off;
+};
+
+__device__ __forceinline__ const double* vec_ptr(const VecRef& r) {
+    if (r.base == nullptr) return nullptr;
+    int64_t lv = (r.level ? (int64_t)(*r.level) : 0) + r.level_off;
+    return r.base + lv * r.stride;
+}
+
+static inline VecRef make_ref(const double* p) { return VecRef{p, nullptr, 0, 0}; }
+static inline VecRef make_ref(const double* p, const int32_t* level, int64_t stride, int32_t off) {
+    return VecRef{p, level, stride, off};
+}
+
+// ---------------------------------------------------------------------------
+// Row partitioning.  gridDim.x blocks each own one contiguous chunk of rows;
+// consecutive chunks go to the same XCD (blocks are dealt round-robin over the 8
+// XCDs, each with a private L2), so neighbouring rows -- which share x-vector
+// halo lines -- hit the same L2.  The remap is bijective for any grid size and
+// only affects speed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_remap(int b, int G) {
+    int q = G >> 3, r = G & 7;
+    int xcd = b & 7, idx = b >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+struct RowRange { int begin, end; };
+
+__device__ __forceinline__ RowRange block_rows(int n) {
+    int G = gridDim.x;
+    int lb = xcd_remap(blockIdx.x, G);
+    int chunk = (n + G - 1) / G;
+    // keep chunks a multiple of the wave size so that wave loads stay aligned
+    chunk = (chunk + WAVE - 1) & ~(WAVE - 1);
+    int b = lb * chunk;
+    int e = b + chunk;
+    if (b > n) b = n;
+    if (e > n) e = n;
+    return RowRange{b, e};
+}
+
+// ---------------------------------------------------------------------------
+// Reductions (wave64 shuffles, then LDS across the block's waves).  All of them
+// return the result in every thread.  smem must hold >= 32 doubles.
+// ---------------------------------------------------------------------------
+struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v, Op op) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+template <class Op>
+__device__ __forceinline__ double block_reduce(double v, Op op, double identity, double* smem) {
+    v = wave_reduce(v, op);
+    int nw = (blockDim.x + WAVE - 1) / WAVE;
+    if (nw == 1) return v;
+    int wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    __syncthreads();  // smem reuse across successive calls
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    double r = identity;
+    for (int w = 0; w < nw; ++w) r = op(r, smem[w]);  // fixed order: deterministic
+    return r;
+}
+
+// Every block reduces the same `count` per-block partials in the same order, so
+// all blocks obtain a bitwise identical value without any atomics.
+template <class Op>
+__device__ __forceinline__ double reduce_partials(const double* part, int count, Op op,
+                                                  double identity, double* smem) {
+    double v = identity;
+    for (int k = threadIdx.x; k < count; k += blockDim.x) v = op(v, part[k]);
+    return block_reduce(v, op, identity, smem);
+}

@@ -1,0 +1,147 @@
+// Internal declarations of libfemfct (gfx950).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <tuple>
+
+#include "../../include/femfct.h"
+
+#define FEMFCT_MAX_W 16          // widest ELL row supported (P1 structured mesh: 7)
+#define FEMFCT_MAX_PARTIALS 2048 // cap on per-kernel block partials (grid-stride beyond)
+
+// ---------------------------------------------------------------------------
+// device-side control block of one low-order solve / step (one per batch member)
+// ---------------------------------------------------------------------------
+struct StepCtl {
+    int32_t flags;        // FEMFCT_FLAG_*
+    int32_t iters;        // Jacobi sweeps that did work
+    int32_t done;         // set when the residual test passed
+    int32_t parity;       // which ping-pong buffer holds the solution (0: xa, 1: xb)
+    double  resid;        // ||r||_inf / ||b||_inf seen by the last active sweep
+    double  bnorm;        // ||b||_inf
+    double  min_rowsum;   // min_i rowsum(L)
+    double  pad;
+};
+
+struct femfct_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // pattern
+    int32_t n = 0;            // rows
+    int32_t W = 0;            // ELL width
+    int64_t nnz_csr = 0;
+    int32_t* d_cols = nullptr;     // [W*n] column of (slot,row); padded entries = row
+    uint8_t* d_tslot = nullptr;    // [W*n] slot of the transposed entry in row cols[s,i]
+    int32_t* d_csr2ell = nullptr;  // [nnz_csr] linear ELL index of every CSR entry
+    std::vector<int32_t> h_indptr, h_indices, h_csr2ell, h_cols;
+    bool structured = false;
+    double a1 = 0, a2 = 0, h = 0;
+    int32_t n_cells = 0, N = 0, order = 0;
+    int32_t* d_d2v = nullptr;      // [n] dof -> vertex (structured, FEniCS order only)
+
+    // constant operators
+    double* d_M = nullptr;    // ELL [W*n]
+    double* d_Ad = nullptr;   // ELL [W*n] (structured only)
+    double* d_ml = nullptr;   // [n]
+    bool have_mass = false;
+
+    // solver settings
+    int solver = FEMFCT_SOLVER_JACOBI;
+    double rel_tol = 1e-13;
+    int max_iters = 400;
+    int sweep_budget = 48;      // adaptive: sweeps enqueued per step
+    bool use_graphs = true;
+
+    // workspace (sized for ws_batch systems)
+    int32_t ws_batch = 0;
+    double *d_L = nullptr, *d_D = nullptr, *d_F = nullptr;           // ELL [B*W*n]
+    double *d_b = nullptr, *d_xa = nullptr, *d_xb = nullptr;          // [B*n]
+    double *d_du = nullptr, *d_y0 = nullptr, *d_y1 = nullptr, *d_y2 = nullptr, *d_rdu = nullptr;
+    double *d_rp = nullptr, *d_rm = nullptr;                          // R+ / R- [B*n]
+    double *d_part = nullptr;                                         // block partials [B*4*MAX_PARTIALS]
+    StepCtl* d_ctl = nullptr;                                         // [B]
+    // host staging for the *_host convenience calls
+    double *d_hA = nullptr, *d_hN = nullptr, *d_hrhs = nullptr, *d_hu = nullptr, *d_hout = nullptr, *d_hcsr = nullptr;
+
+    // hipGraph cache of captured kernel sequences, keyed by the bit patterns of every
+    // captured argument (pointers, scalars, batch, sweep budget)
+    typedef std::vector<uint64_t> GraphKey;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+
+    // trajectory workspace
+    int32_t tr_batch = 0, tr_steps = 0;
+    double *d_trA = nullptr, *d_trN = nullptr, *d_trRhs = nullptr;  // per-step operators [B*W*n], [B*n]
+    int32_t* d_level = nullptr;                                     // [2]: current level, step ordinal
+    StepCtl* d_log = nullptr;                                       // [tr_steps * tr_batch]
+    std::vector<StepCtl> h_log;                                     // last trajectory's log
+    int32_t log_steps = 0, log_batch = 0;
+
+    // scratch for reductions (kernels_pgd.hip)
+    double* d_scratch = nullptr;
+    size_t scratch_count = 0;
+};
+
+// error helpers ---------------------------------------------------------------
+int femfct_fail(femfct_ctx* ctx, int code, const char* fmt, ...);
+#define HIP_TRY(ctx, expr)                                                          \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return femfct_fail((ctx), FEMFCT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                               hipGetErrorString(_e), __FILE__, __LINE__);          \
+    } while (0)
+#define ARG_TRY(ctx, cond, msg)                                                     \
+    do {                                                                            \
+        if (!(cond)) return femfct_fail((ctx), FEMFCT_ERR_INVALID, "%s", msg);      \
+    } while (0)
+
+int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch);
+void femfct_drop_graphs(femfct_ctx* ctx);
+void femfct_release_pattern(femfct_ctx* ctx);
+int femfct_round_budget(const femfct_ctx* ctx, int b);
+
+// graph-key helpers
+static inline uint64_t key_bits(const void* p) { return (uint64_t)(uintptr_t)p; }
+static inline uint64_t key_bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline uint64_t key_bits(int64_t v) { return (uint64_t)v; }
+static inline uint64_t key_bits(int32_t v) { return (uint64_t)(int64_t)v; }
+// Run `enqueue` (a callable that launches kernels on ctx->stream) through a cached hipGraph.
+template <class F>
+int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue);
+
+// kernel launchers (kernels_step.hip) -----------------------------------------
+struct LaunchGeom { dim3 grid; dim3 block; };
+LaunchGeom femfct_geom(const femfct_ctx* ctx, int32_t batch);
+
+int femfct_enqueue_step(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared,
+                        const double* rhs, const double* u_n, double dt, double* u_out,
+                        int32_t batch, int32_t budget);
+
+template <class F>
+int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue) {
+    if (!ctx->use_graphs) return enqueue();
+    auto it = ctx->graphs.find(key);
+    if (it == ctx->graphs.end()) {
+        if (ctx->graphs.size() > 64) femfct_drop_graphs(ctx);
+        hipGraph_t graph = nullptr;
+        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue();
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc != FEMFCT_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        it = ctx->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));
+    return FEMFCT_OK;
+}

@@ -1,0 +1,464 @@
+// FEM-FCT step operator on gfx950: hand-written HIP kernels for
+//   FCT_alg_ref                 /root/reference/helpers.py:1715-1872
+//   ChebSI                      /root/reference/helpers.py:143-185
+//   artificial_diffusion_mat    /root/reference/helpers.py:206-242
+//
+// One thread owns one matrix row (ELL, slot-major => every matrix/index load of
+// a wave is one coalesced 512-byte line per slot); neighbour values are gathered
+// through L1/L2.  The flux F_ij is recomputed per row from the row's own data
+// (F_ji = -F_ij), so nothing is scattered and no floating-point atomics exist:
+// results are bitwise reproducible run to run.  The only cross-thread
+// reductions are max/min (order independent), done with wave64 shuffles, LDS,
+// and per-block partials re-reduced by every block of the consuming kernel.
+//
+// Kernel sequence of one step (all bandwidth bound; bytes per row, W = 7):
+//   k_build_low   A -> D, L, b, x0, row-sum / ||b|| partials        W*37+32  B
+//   k_jacobi  xI  x <- D^-1 (b - offdiag(L) x), residual partials   W*12+32  B
+//   k_dudt_rhs    r = rhs - A u_L ; first Chebyshev iterate         W*12+40  B
+//   k_cheb   x19  Chebyshev semi-iteration on M                     W*12+40  B
+//   k_flux        F_ij, P+-, Q+-, R+-                               W*28+40  B
+//   k_limit       alpha_ij, Fbar, u^{n+1}                           W*12+40  B
+#include "femfct_internal.h"
+#include "device_utils.h"
+
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ const double* sel(const StepCtl* ctl, const double* xa, const double* xb) {
+    return ctl->parity ? xb : xa;
+}
+
+// ---------------------------------------------------------------------------
+// k_build_low: artificial diffusion + low-order operator + rhs (helpers.py:1769-1780)
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void k_build_low(int n, int Wrt, const int32_t* __restrict__ cols,
+                            const uint8_t* __restrict__ tslot, const double* __restrict__ A_,
+                            const double* __restrict__ N_, int nshared, VecRef rhs_ref, VecRef u_ref,
+                            int64_t rhs_bstride, int64_t u_bstride,
+                            const double* __restrict__ ml, double dt, double* __restrict__ L_,
+                            double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
+                            double* __restrict__ part, StepCtl* __restrict__ ctl_) {
+    __shared__ double smem[32];
+    const int W = WT ? WT : Wrt;
+    const int bz = blockIdx.y;
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* A = A_ + moff;
+    const double* Nm = N_ ? N_ + (nshared ? 0 : moff) : nullptr;
+    const double* rhs = vec_ptr(rhs_ref);
+    if (rhs) rhs += bz * rhs_bstride;
+    const double* u = vec_ptr(u_ref) + bz * u_bstride;
+    double* L = L_ + moff;
+    double* D = D_ + moff;
+    double* b = b_ + voff;
+    double* x0 = x0_ + voff;
+
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        StepCtl* c = ctl_ + bz;
+        c->flags = 0; c->iters = 0; c->done = 0; c->parity = 0; c->resid = 0.0; c->bnorm = 0.0;
+        c->min_rowsum = 0.0;
+    }
+
+    RowRange rr = block_rows(n);
+    double bmax = 0.0, rsmin = INFINITY;
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double dsum = 0.0, rs = 0.0;
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            int j = cols[idx];
+            int ts = tslot[idx];
+            double a = A[idx];
+            double at = A[(int64_t)ts * n + j];
+            double d = (j != i) ? fmax(0.0, fmax(a, at)) : 0.0;   // d_ij = max(0, a_ij, a_ji)
+            dsum += d;
+            double l = dt * (a - d);
+            if (Nm) l += dt * Nm[idx];
+            L[idx] = l;
+            D[idx] = d;
+            rs += l;
+        }
+        double mli = ml[i];
+        double ld = mli + dt * (A[i] + dsum);                      // d_ii = -sum_j d_ij
+        if (Nm) ld += dt * Nm[i];
+        L[i] = ld;
+        D[i] = -dsum;
+        rs += ld;
+        double ui = u[i];
+        double bi = mli * ui + (rhs ? dt * rhs[i] : 0.0);
+        b[i] = bi;
+        x0[i] = ui;
+        bmax = fmax(bmax, fabs(bi));
+        rsmin = fmin(rsmin, rs);
+    }
+    bmax = block_reduce(bmax, OpMax(), 0.0, smem);
+    rsmin = block_reduce(rsmin, OpMin(), INFINITY, smem);
+    if (threadIdx.x == 0) {
+        double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+        p[2 * FEMFCT_MAX_PARTIALS + blockIdx.x] = bmax;
+        p[3 * FEMFCT_MAX_PARTIALS + blockIdx.x] = rsmin;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_jacobi: one sweep of x <- Dg^-1 (b - O x) for the M-matrix L = Dg + O
+// (replaces the per-step SuperLU factorisation, helpers.py:1782).
+// Since x_new - x_old = Dg^-1 r(x_old), every sweep also yields the true residual
+// of its input iterate; convergence is decided on the device from those.
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void k_jacobi(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ L_,
+                         const double* __restrict__ b_, double* __restrict__ xa_, double* __restrict__ xb_,
+                         double* __restrict__ part, StepCtl* __restrict__ ctl_, int sweep, double rel_tol) {
+    __shared__ double smem[32];
+    const int W = WT ? WT : Wrt;
+    const int bz = blockIdx.y;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int G = gridDim.x;
+    double bnorm;
+    if (sweep == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, G, OpMin(), INFINITY, smem);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rmax = reduce_partials(p + ((sweep - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
+        if (rmax <= rel_tol * bnorm) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = sweep & 1; ctl->iters = sweep;
+                ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* b = b_ + voff;
+    const double* xin = ((sweep & 1) ? xb_ : xa_) + voff;
+    double* xout = ((sweep & 1) ? xa_ : xb_) + voff;
+
+    RowRange rr = block_rows(n);
+    double rmax = 0.0;
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double acc = b[i];
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            acc -= L[idx] * xin[cols[idx]];
+        }
+        double ld = L[i];
+        double xi = xin[i];
+        double xn = acc / ld;
+        xout[i] = xn;
+        rmax = fmax(rmax, fabs(acc - ld * xi));   // |r_i(x_in)|
+    }
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) p[(sweep & 1) * FEMFCT_MAX_PARTIALS + blockIdx.x] = rmax;
+}
+
+// Finalise the solve bookkeeping when the sweep budget ran out before `done`.
+__device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, int budget, double rel_tol,
+                                               double* smem) {
+    if (ctl->done) return;
+    double rmax = reduce_partials(p + ((budget - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
+    // every block computes the same values; block 0 publishes them for later kernels' diagnostics.
+    // parity is derived locally below (ctl->parity is only written here by block 0 and read by
+    // later kernels, never by other blocks of this kernel).
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double bn = ctl->bnorm;
+        ctl->iters = budget;
+        ctl->resid = bn > 0.0 ? rmax / bn : 0.0;
+        if (!(rmax <= rel_tol * bn)) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_dudt_rhs: r = rhs - A u_L (helpers.py:1814) fused with Chebyshev iterate 1
+// (y_1 = omega_1 * r / (1.25 diag M), helpers.py:175-182 with y_0 = y_-1 = 0).
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void k_dudt_rhs(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ A_,
+                           VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
+                           const double* __restrict__ xa_, const double* __restrict__ xb_,
+                           double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
+                           double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, double rel_tol,
+                           double md_scale, double omega1) {
+    __shared__ double smem[32];
+    const int W = WT ? WT : Wrt;
+    const int bz = blockIdx.y;
+    StepCtl* ctl = ctl_ + bz;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    // solution buffer: decided by the sweep that detected convergence, else by the budget parity
+    const int parity = ctl->done ? ctl->parity : (budget & 1);
+    finalize_solve(ctl, p, gridDim.x, budget, rel_tol, smem);
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* A = A_ + moff;
+    const double* x = (parity ? xb_ : xa_) + voff;
+    const double* rhs = vec_ptr(rhs_ref);
+    if (rhs) rhs += bz * rhs_bstride;
+    double* ulow = ulow_ + voff;
+    double* rdu = rdu_ + voff;
+    double* y1 = y1_ + voff;
+    RowRange rr = block_rows(n);
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double xi = x[i];
+        double acc = A[i] * xi;
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            acc += A[idx] * x[cols[idx]];
+        }
+        double r = -acc + (rhs ? rhs[i] : 0.0);
+        rdu[i] = r;
+        ulow[i] = xi;               // stable home of u_L for the flux/limit kernels
+        y1[i] = omega1 * (r / (md_scale * M[i]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_cheb: one Chebyshev semi-iteration step (helpers.py:175-184)
+//   r = b - M y_mid ; z = r / Md ; y_new = omega (z + y_mid - y_old) + y_old
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void k_cheb(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
+                       const double* __restrict__ b_, const double* __restrict__ ymid_,
+                       const double* __restrict__ yold_, double* __restrict__ ynew_, double omega,
+                       double md_scale) {
+    const int W = WT ? WT : Wrt;
+    const int64_t voff = (int64_t)blockIdx.y * n;
+    const double* b = b_ + voff;
+    const double* ymid = ymid_ ? ymid_ + voff : nullptr;   // null: y_mid = 0 (first iterate)
+    const double* yold = yold_ ? yold_ + voff : nullptr;   // null: y_old = 0
+    double* ynew = ynew_ + voff;
+    RowRange rr = block_rows(n);
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double md = M[i];
+        double ym = ymid ? ymid[i] : 0.0;
+        double acc = md * ym;
+        if (ymid) {
+#pragma unroll
+            for (int s = 1; s < W; ++s) {
+                int64_t idx = (int64_t)s * n + i;
+                acc += M[idx] * ymid[cols[idx]];
+            }
+        }
+        double r = b[i] - acc;
+        double z = r / (md_scale * md);
+        double yo = yold ? yold[i] : 0.0;
+        ynew[i] = omega * (z + ym - yo) + yo;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_flux: raw antidiffusive fluxes + Zalesak P/Q/R (helpers.py:1818-1851)
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void k_flux(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
+                       const double* __restrict__ D_, const double* __restrict__ ulow_,
+                       const double* __restrict__ du_, const double* __restrict__ ml, double dt,
+                       double* __restrict__ F_, double* __restrict__ rp_, double* __restrict__ rm_) {
+    const int W = WT ? WT : Wrt;
+    const int bz = blockIdx.y;
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* D = D_ + moff;
+    const double* ulow = ulow_ + voff;
+    const double* du = du_ + voff;
+    double* F = F_ + moff;
+    double* rp = rp_ + voff;
+    double* rm = rm_ + voff;
+    RowRange rr = block_rows(n);
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double ui = ulow[i], dui = du[i];
+        double pp = 0.0, pm = 0.0, umax = ui, umin = ui;
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            int j = cols[idx];
+            double uj = ulow[j];
+            double f = M[idx] * (dui - du[j]) + D[idx] * (ui - uj);
+            F[idx] = f;
+            pp += fmax(f, 0.0);
+            pm += fmin(f, 0.0);
+            umax = fmax(umax, uj);
+            umin = fmin(umin, uj);
+        }
+        double mli = ml[i];
+        double qp = umax - ui, qm = umin - ui;
+        rp[i] = (pp != 0.0) ? fmin(1.0, mli * qp / (dt * pp)) : 1.0;
+        rm[i] = (pm != 0.0) ? fmin(1.0, mli * qm / (dt * pm)) : 1.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_limit: alpha_ij, limited flux sum and explicit correction (helpers.py:1860-1870)
+// ---------------------------------------------------------------------------
+template <int WT>
+__global__ void k_limit(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ F_,
+                        const double* __restrict__ rp_, const double* __restrict__ rm_,
+                        const double* __restrict__ ulow_, const double* __restrict__ ml, double dt,
+                        VecRef out_ref, int64_t out_bstride) {
+    const int W = WT ? WT : Wrt;
+    const int bz = blockIdx.y;
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* F = F_ + moff;
+    const double* rp = rp_ + voff;
+    const double* rm = rm_ + voff;
+    const double* ulow = ulow_ + voff;
+    double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
+    RowRange rr = block_rows(n);
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double rpi = rp[i], rmi = rm[i];
+        double fbar = 0.0;
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            int j = cols[idx];
+            double f = F[idx];
+            double a = (f > 0.0) ? fmin(rpi, rm[j]) : fmin(rmi, rp[j]);
+            fbar += a * f;
+        }
+        out[i] = ulow[i] + dt * fbar / ml[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone helpers: artificial diffusion only, SpMV
+// ---------------------------------------------------------------------------
+__global__ void k_artdiff(int n, int W, const int32_t* __restrict__ cols, const uint8_t* __restrict__ tslot,
+                          const double* __restrict__ K_, double* __restrict__ D_) {
+    const int64_t moff = (int64_t)blockIdx.y * W * n;
+    const double* K = K_ + moff;
+    double* D = D_ + moff;
+    RowRange rr = block_rows(n);
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double dsum = 0.0;
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            int j = cols[idx];
+            double k = K[idx], kt = K[(int64_t)tslot[idx] * n + j];
+            double d = (j != i) ? fmax(0.0, fmax(-k, -kt)) : 0.0;
+            D[idx] = d;
+            dsum += d;
+        }
+        D[i] = -dsum;
+    }
+}
+
+__global__ void k_spmv(int n, int W, const int32_t* __restrict__ cols, const double* __restrict__ A_,
+                       const double* __restrict__ x_, double alpha, double beta, double* __restrict__ y_) {
+    const int64_t moff = (int64_t)blockIdx.y * W * n, voff = (int64_t)blockIdx.y * n;
+    const double* A = A_ + moff;
+    const double* x = x_ + voff;
+    double* y = y_ + voff;
+    RowRange rr = block_rows(n);
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double acc = A[i] * x[i];
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            acc += A[idx] * x[cols[idx]];
+        }
+        y[i] = (beta != 0.0) ? alpha * acc + beta * y[i] : alpha * acc;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+LaunchGeom femfct_geom(const femfct_ctx* ctx, int32_t batch) {
+    int bs = (ctx->n <= 65536) ? 64 : 256;
+    int64_t g = ((int64_t)ctx->n + bs - 1) / bs;
+    if (g > FEMFCT_MAX_PARTIALS) g = FEMFCT_MAX_PARTIALS;
+    if (g < 1) g = 1;
+    return LaunchGeom{dim3((unsigned)g, (unsigned)batch, 1), dim3((unsigned)bs, 1, 1)};
+}
+
+// Chebyshev weights of helpers.py:170-179 (omega_1 from the else-branch with omega = 0).
+static void cheb_omegas(int iters, double lmin, double lmax, std::vector<double>& om) {
+    double rho = (lmax - lmin) / (lmax + lmin);
+    double w = 0.0;
+    om.resize(iters);
+    for (int k = 1; k <= iters; ++k) {
+        if (k == 2) w = 1.0 / (1.0 - rho * rho / 2.0);
+        else w = 1.0 / (1.0 - (w * rho * rho) / 4.0);
+        om[k - 1] = w;
+    }
+}
+
+#define LAUNCH_W(kern, geom, stream, ...)                                                  \
+    do {                                                                                   \
+        if (ctx->W == 7) hipLaunchKernelGGL((kern<7>), geom.grid, geom.block, 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kern<0>), geom.grid, geom.block, 0, stream, __VA_ARGS__);  \
+    } while (0)
+
+int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int iters, double lmin, double lmax,
+                        int32_t batch, bool first_done_in_y1) {
+    // rotating buffers y0,y1,y2; iterate k reads mid=buf[(k-1)%3], old=buf[(k-2)%3], writes buf[k%3]
+    LaunchGeom g = femfct_geom(ctx, batch);
+    std::vector<double> om;
+    cheb_omegas(iters, lmin, lmax, om);
+    const double md_scale = (lmin + lmax) / 2.0;
+    double* buf[3] = {ctx->d_y0, ctx->d_y1, ctx->d_y2};
+    int n = ctx->n, W = ctx->W;
+    for (int k = 1; k <= iters; ++k) {
+        if (k == 1 && first_done_in_y1) continue;  // produced by k_dudt_rhs into buf[1]
+        const double* mid = (k >= 2) ? buf[(k - 1) % 3] : nullptr;
+        const double* old = (k >= 3) ? buf[(k - 2) % 3] : nullptr;
+        double* out = (k == iters) ? y_out : buf[k % 3];
+        LAUNCH_W(k_cheb, g, ctx->stream, n, W, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale);
+    }
+    return FEMFCT_OK;
+}
+
+// Enqueue the whole step with level-indirected in/out vectors (trajectory drivers) --------
+int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, VecRef rhs,
+                            int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
+                            int64_t out_bstride, int32_t batch, int32_t budget) {
+    LaunchGeom g = femfct_geom(ctx, batch);
+    hipStream_t st = ctx->stream;
+    int n = ctx->n, W = ctx->W;
+    LAUNCH_W(k_build_low, g, st, n, W, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n, rhs_bstride,
+             u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
+    for (int s = 0; s < budget; ++s)
+        LAUNCH_W(k_jacobi, g, st, n, W, ctx->d_cols, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, ctx->d_part,
+                 ctx->d_ctl, s, ctx->rel_tol);
+    // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
+    double* ulow = ctx->d_b;
+    LAUNCH_W(k_dudt_rhs, g, st, n, W, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
+             ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, budget, ctx->rel_tol, 1.25, 1.0);
+    femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
+    LAUNCH_W(k_flux, g, st, n, W, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt, ctx->d_F,
+             ctx->d_rp, ctx->d_rm);
+    LAUNCH_W(k_limit, g, st, n, W, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt, u_out,
+             out_bstride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return FEMFCT_OK;
+}
+
+int femfct_enqueue_step(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, const double* rhs,
+                        const double* u_n, double dt, double* u_out, int32_t batch, int32_t budget) {
+    return femfct_enqueue_step_ref(ctx, A, N, nshared, make_ref(rhs), ctx->n, make_ref(u_n), ctx->n, dt,
+                                   make_ref(u_out), ctx->n, batch, budget);
+}
+
+int femfct_enqueue_artdiff(femfct_ctx* ctx, const double* K, double* D, int32_t batch) {
+    LaunchGeom g = femfct_geom(ctx, batch);
+    hipLaunchKernelGGL(k_artdiff, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->W, ctx->d_cols, ctx->d_tslot, K, D);
+    return FEMFCT_OK;
+}
+
+int femfct_enqueue_spmv(femfct_ctx* ctx, const double* A, const double* x, double alpha, double beta, double* y,
+                        int32_t batch) {
+    LaunchGeom g = femfct_geom(ctx, batch);
+    hipLaunchKernelGGL(k_spmv, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->W, ctx->d_cols, A, x, alpha, beta, y);
+    return FEMFCT_OK;
+}

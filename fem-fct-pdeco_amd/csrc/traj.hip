@@ -1,0 +1,203 @@
+// Forward / adjoint trajectory sweeps resident on one GPU.
+//
+// One time step = [assemble the step's flux matrix] -> [FCT step] -> [advance level];
+// the whole sequence is captured once into a hipGraph and replayed num_steps times.
+// The current time level lives in a device-side counter that the captured kernels
+// read (VecRef), so the replayed graph needs no per-step host patching.
+//
+//   solid-body rotation + drift control
+//     forward  /root/reference/advection_solidbody_FCT_PDECO_finaltime.py:175-193
+//     adjoint  /root/reference/advection_solidbody_FCT_PDECO_finaltime.py:200-221
+//              /root/reference/advection_solidbody_FCT_PDECO_alltime.py:232-259
+#include "femfct_internal.h"
+#include "device_utils.h"
+
+#include <algorithm>
+
+int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, VecRef rhs,
+                            int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
+                            int64_t out_bstride, int32_t batch, int32_t budget);
+int femfct_enqueue_ops_solidbody(femfct_ctx* ctx, const double* Arot, VecRef c_ref, int64_t c_bstride, double eps,
+                                 double sigma, double rot_scale, double bx, double by, double* A, int32_t batch);
+int femfct_enqueue_mass_diff(femfct_ctx* ctx, VecRef a, int64_t a_bstride, VecRef b, int64_t b_bstride, double* out,
+                             int32_t batch);
+int femfct_enqueue_set_level(femfct_ctx* ctx, int32_t* level, int value);
+int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
+                         double* out);
+
+namespace {
+
+// end of a step: log the solver control blocks, then move the level counter
+__global__ void k_step_end(int32_t* level, int delta, const StepCtl* __restrict__ ctl, StepCtl* __restrict__ log,
+                           int batch) {
+    int ord = level[1];
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) log[(int64_t)ord * batch + b] = ctl[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        level[0] += delta;
+        level[1] = ord + 1;
+    }
+}
+
+int ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps) {
+    int rc = femfct_ensure_workspace(ctx, batch);
+    if (rc != FEMFCT_OK) return rc;
+    if (batch > ctx->tr_batch) {
+        femfct_drop_graphs(ctx);
+        if (ctx->d_trA) hipFree(ctx->d_trA);
+        if (ctx->d_trN) hipFree(ctx->d_trN);
+        if (ctx->d_trRhs) hipFree(ctx->d_trRhs);
+        ctx->d_trA = ctx->d_trN = ctx->d_trRhs = nullptr;
+        size_t nv = (size_t)batch * ctx->n, nm = nv * ctx->W;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trA, sizeof(double) * nm));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trN, sizeof(double) * nm));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trRhs, sizeof(double) * nv));
+        if (ctx->d_log) hipFree(ctx->d_log);
+        ctx->d_log = nullptr;
+        ctx->tr_steps = 0;
+        ctx->tr_batch = batch;
+    }
+    if (!ctx->d_level) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_level, sizeof(int32_t) * 2));
+    if (steps > ctx->tr_steps || !ctx->d_log) {
+        femfct_drop_graphs(ctx);
+        if (ctx->d_log) hipFree(ctx->d_log);
+        ctx->d_log = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_log, sizeof(StepCtl) * (size_t)steps * ctx->tr_batch));
+        ctx->tr_steps = steps;
+    }
+    return FEMFCT_OK;
+}
+
+// Replays `step` num_steps times, then inspects the per-step solver log; if the
+// sweep budget was too small anywhere the whole sweep is repeated with a larger one.
+template <class Begin, class Step>
+int run_sweep(femfct_ctx* ctx, int32_t num_steps, int32_t batch, int level0, Begin&& begin, Step&& step) {
+    for (int attempt = 0;; ++attempt) {
+        const int budget = femfct_round_budget(ctx, ctx->sweep_budget);
+        int rc = begin();
+        if (rc != FEMFCT_OK) return rc;
+        int32_t init[2] = {level0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_level, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        for (int32_t k = 0; k < num_steps; ++k) {
+            rc = step(budget);
+            if (rc != FEMFCT_OK) return rc;
+        }
+        ctx->h_log.resize((size_t)num_steps * batch);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_log.data(), ctx->d_log, sizeof(StepCtl) * ctx->h_log.size(),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->log_steps = num_steps;
+        ctx->log_batch = batch;
+        int worst = 0;
+        bool short_budget = false;
+        double worst_res = 0.0;
+        for (const StepCtl& c : ctx->h_log) {
+            worst = std::max(worst, c.iters);
+            if (c.flags & FEMFCT_FLAG_SOLVER_BUDGET) { short_budget = true; worst_res = std::max(worst_res, c.resid); }
+        }
+        if (!short_budget) {
+            ctx->sweep_budget = std::min(ctx->max_iters, std::max(8, worst + worst / 4 + 4));
+            return FEMFCT_OK;
+        }
+        if (budget >= ctx->max_iters)
+            return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
+                               "low-order solve: residual %.3e after %d sweeps (tol %.1e)", worst_res, budget,
+                               ctx->rel_tol);
+        ctx->sweep_budget = std::min(ctx->max_iters, budget * 2);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
+                             double* u_traj, int32_t num_steps, double dt, double eps, double rot_scale, double bx,
+                             double by, int32_t batch) {
+    ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
+    ARG_TRY(ctx, c_traj && u_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
+    ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
+    int rc = ensure_traj_ws(ctx, batch, num_steps);
+    if (rc != FEMFCT_OK) return rc;
+    const int64_t n = ctx->n, tstride = (int64_t)(num_steps + 1) * n;
+    const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;  // any valid ELL array; multiplied by 0
+    int32_t* lv = ctx->d_level;
+    auto begin = [&]() { return FEMFCT_OK; };
+    auto step = [&](int budget) {
+        femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
+                                 key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
+                                 key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
+        return femfct_run_graph(ctx, key, [&]() {
+            // control at level n+1 (finaltime.py:185), state from level n into level n+1
+            femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
+                                         rot_scale, bx, by, ctx->d_trA, batch);
+            int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, make_ref(nullptr), 0,
+                                            make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
+                                            tstride, batch, budget);
+            if (r != FEMFCT_OK) return r;
+            hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, lv, 1, ctx->d_ctl, ctx->d_log, batch);
+            return FEMFCT_OK;
+        });
+    };
+    return run_sweep(ctx, num_steps, batch, 0, begin, step);
+}
+
+int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
+                             const double* u_traj, const double* uhat, double* p_traj, int32_t num_steps, double dt,
+                             double eps, double rot_scale, double bx, double by, int32_t alltime, int32_t batch) {
+    ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
+    ARG_TRY(ctx, c_traj && u_traj && uhat && p_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
+    ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
+    int rc = ensure_traj_ws(ctx, batch, num_steps);
+    if (rc != FEMFCT_OK) return rc;
+    const int64_t n = ctx->n, tstride = (int64_t)(num_steps + 1) * n;
+    const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;
+    int32_t* lv = ctx->d_level;
+    auto begin = [&]() {
+        // terminal condition: p(T) = uhat_T - u(T) (finaltime.py:201) or 0 (alltime.py:232)
+        for (int32_t b = 0; b < batch; ++b) {
+            double* pT = p_traj + b * tstride + (int64_t)num_steps * n;
+            if (alltime) HIP_TRY(ctx, hipMemsetAsync(pT, 0, sizeof(double) * n, ctx->stream));
+            else femfct_enqueue_axpby(ctx, n, 1.0, uhat + (int64_t)b * n, -1.0, u_traj + b * tstride + (int64_t)num_steps * n, pT);
+        }
+        return FEMFCT_OK;
+    };
+    auto step = [&](int budget) {
+        femfct_ctx::GraphKey key{(uint64_t)3, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
+                                 key_bits(uhat), key_bits(p_traj), key_bits(num_steps), key_bits(dt), key_bits(eps),
+                                 key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
+                                 key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
+        return femfct_run_graph(ctx, key, [&]() {
+            // level counter = n: control c_n (finaltime.py:213), p_{n+1} -> p_n
+            femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
+                                         rot_scale, bx, by, ctx->d_trA, batch);
+            VecRef rhs = make_ref(nullptr);
+            if (alltime) {  // rhs = assemble((uhat_n - u_n) v dx)  (alltime.py:257)
+                femfct_enqueue_mass_diff(ctx, make_ref(uhat, lv, n, 0), tstride, make_ref(u_traj, lv, n, 0), tstride,
+                                         ctx->d_trRhs, batch);
+                rhs = make_ref(ctx->d_trRhs);
+            }
+            int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
+                                            dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
+            if (r != FEMFCT_OK) return r;
+            hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, lv, -1, ctx->d_ctl, ctx->d_log, batch);
+            return FEMFCT_OK;
+        });
+    };
+    return run_sweep(ctx, num_steps, batch, num_steps - 1, begin, step);
+}
+
+// per-step solver diagnostics of the most recent trajectory sweep: info[step*batch + b]
+int femfct_traj_info(femfct_ctx* ctx, femfct_step_info* info_host, int32_t num_steps, int32_t batch) {
+    ARG_TRY(ctx, ctx && info_host, "null argument");
+    ARG_TRY(ctx, num_steps == ctx->log_steps && batch == ctx->log_batch, "no matching trajectory log");
+    for (size_t k = 0; k < ctx->h_log.size(); ++k) {
+        info_host[k].flags = ctx->h_log[k].flags;
+        info_host[k].solver_iters = ctx->h_log[k].iters;
+        info_host[k].solver_resid = ctx->h_log[k].resid;
+        info_host[k].min_rowsum = ctx->h_log[k].min_rowsum;
+    }
+    return FEMFCT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+/*
+ * femfct.h -- C ABI of libfemfct.so, the MI355X (gfx950) FEM-FCT forward/adjoint
+ * time-stepping core.
+ *
+ * The reference (KarolinaBenkova/FEM-FCT-PDECO) has no FFI layer: its boundary
+ * is the Python call signature of helpers.py.  Each entry point below names the
+ * reference interface (file:line under /root/reference) it replaces; the Python
+ * mirror of those signatures lives in fem-fct-pdeco_amd/ and binds this header
+ * through ctypes.
+ *
+ * Conventions
+ *   - plain C, no C++ types or exceptions cross the ABI; every function returns
+ *     an int status (FEMFCT_OK = 0) unless documented otherwise;
+ *   - one femfct_ctx = one GPU + one HIP stream; a ctx is not thread-safe,
+ *     distinct ctxs are independent (one process per GPU);
+ *   - the caller owns host buffers; device buffers are either owned by the ctx
+ *     or allocated by the caller (femfct_malloc, or any hipMalloc'd pointer such
+ *     as torch.Tensor.data_ptr());
+ *   - all arithmetic is IEEE float64; indices are int32;
+ *   - "dev" pointers are device pointers, "host" pointers are host pointers;
+ *   - all work is enqueued on the ctx stream; functions taking host output
+ *     buffers synchronise before returning, pure-device functions do not.
+ *
+ * Data layout (device)
+ *   vector        double[n]                      (DoF order chosen at pattern set-up)
+ *   trajectory    double[(Nt+1)*n], level k at [k*n,(k+1)*n)   (helpers.py:563-564)
+ *   ELL matrix    double[W*n], slot-major: entry (row i, slot s) at [s*n+i];
+ *                 slot 0 is the diagonal; unused slots have column i and value 0
+ *   batch         B independent systems: vector b at [b*n], ELL b at [b*W*n],
+ *                 trajectory b at [b*(Nt+1)*n]
+ */
+#ifndef FEMFCT_H
+#define FEMFCT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEMFCT_ABI_VERSION 1
+
+typedef struct femfct_ctx femfct_ctx;
+
+/* status codes */
+#define FEMFCT_OK                 0
+#define FEMFCT_ERR_INVALID        1   /* bad argument / call order (ValueError in the Python mirror) */
+#define FEMFCT_ERR_HIP            2   /* HIP runtime error, text in femfct_last_error */
+#define FEMFCT_ERR_NOT_CONVERGED  3   /* an iterative solve missed its tolerance */
+#define FEMFCT_ERR_NOMEM          4
+
+/* femfct_step_info.flags */
+#define FEMFCT_FLAG_MMATRIX_ROWSUM 1  /* some row sum of the low-order matrix <= 0:
+                                         the "3: False" diagnostic of helpers.py:1796-1799 */
+#define FEMFCT_FLAG_SOLVER_BUDGET  2  /* sweep/iteration budget exhausted before tolerance */
+
+/* DoF numbering of the structured mesh */
+#define FEMFCT_ORDER_VERTEX 0         /* iy*N+ix (dolfin vertex order) */
+#define FEMFCT_ORDER_FENICS 1         /* FEniCS CG1 dof order: rank of (ix-iy, iy) */
+
+/* low-order solver selection */
+#define FEMFCT_SOLVER_JACOBI   0      /* Jacobi sweeps, device-side convergence test */
+#define FEMFCT_SOLVER_BICGSTAB 1      /* Jacobi-preconditioned BiCGStab */
+
+typedef struct femfct_step_info {
+    int32_t flags;          /* FEMFCT_FLAG_* */
+    int32_t solver_iters;   /* sweeps / iterations used by the low-order solve */
+    double  solver_resid;   /* ||b - L x||_inf / ||b||_inf of the iterate before the last sweep */
+    double  min_rowsum;     /* min_i sum_j L_ij (helpers.py:1796) */
+} femfct_step_info;
+
+/* ------------------------------------------------------------------ context */
+int         femfct_abi_version(void);
+int         femfct_create(femfct_ctx** ctx, int device_id);
+int         femfct_destroy(femfct_ctx* ctx);
+const char* femfct_last_error(const femfct_ctx* ctx);
+int         femfct_synchronize(femfct_ctx* ctx);
+void*       femfct_stream(femfct_ctx* ctx);                 /* hipStream_t */
+int         femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters);
+int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay of the step sequence (default on) */
+
+/* device memory helpers (so that a ctypes-only host needs no other GPU library) */
+int femfct_malloc(femfct_ctx* ctx, void** dev_ptr, size_t bytes);
+int femfct_free(femfct_ctx* ctx, void* dev_ptr);
+int femfct_memcpy_h2d(femfct_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int femfct_memcpy_d2h(femfct_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int femfct_memcpy_d2d(femfct_ctx* ctx, void* dev_dst, const void* dev_src, size_t bytes);
+int femfct_memset0(femfct_ctx* ctx, void* dev_ptr, size_t bytes);
+
+/* ----------------------------------------------------------------- pattern
+ * Replaces find_node_neighbours (helpers.py:271-307) + the implicit CSR pattern
+ * of assemble_sparse (helpers.py:87-104).  The pattern must be structurally
+ * symmetric and contain the diagonal. */
+int femfct_set_pattern_csr(femfct_ctx* ctx, int32_t n, const int32_t* indptr_host,
+                           const int32_t* indices_host);
+/* RectangleMesh(Point(a1,a1),Point(a2,a2),n_cells,n_cells) + FunctionSpace(mesh,'CG',1)
+ * (advection_solidbody_FCT_PDECO_finaltime.py:63-64); also assembles M, M_lumped and
+ * the stiffness matrix Ad on the device (helpers.py:553-555). */
+int femfct_set_mesh_square(femfct_ctx* ctx, double a1, double a2, int32_t n_cells, int32_t order);
+int32_t femfct_n(const femfct_ctx* ctx);
+int32_t femfct_ell_width(const femfct_ctx* ctx);
+/* ELL structure back to the host (tests, INTEGRATION): cols[W*n] */
+int femfct_get_ell_cols(femfct_ctx* ctx, int32_t* cols_host);
+
+/* CSR values on the registered pattern (host) <-> ELL values (device) */
+int femfct_csr_to_ell(femfct_ctx* ctx, const double* csr_vals_host, double* ell_dev);
+int femfct_ell_to_csr(femfct_ctx* ctx, const double* ell_dev, double* csr_vals_host);
+/* mass matrix M (CSR values on the pattern) and diag of row_lump(M) (helpers.py:309-328)
+ * for a generic pattern; not needed after femfct_set_mesh_square */
+int femfct_set_mass(femfct_ctx* ctx, const double* M_csr_vals_host, const double* ml_host);
+/* device pointers to the ctx-owned constant operators (ELL / vector) */
+const double* femfct_mass_ell(const femfct_ctx* ctx);
+const double* femfct_stiffness_ell(const femfct_ctx* ctx);
+const double* femfct_lumped_mass(const femfct_ctx* ctx);
+
+/* ----------------------------------------------------------- step operator */
+/* FCT_alg_ref(A, rhs, u_n, dt, nodes, M, M_lumped, dof_neighbors, non_flux_mat)
+ * helpers.py:1715-1872.  All pointers are device pointers; N_ell and rhs may be
+ * NULL (= zero).  batch >= 1 independent systems (see layout above); N_shared != 0
+ * means one N_ell is shared by the whole batch.  Asynchronous on the ctx stream. */
+int femfct_fct_step(femfct_ctx* ctx, const double* A_ell, const double* N_ell, int32_t N_shared,
+                    const double* rhs, const double* u_n, double dt, double* u_out, int32_t batch);
+/* diagnostics of the most recent femfct_fct_step (synchronises) */
+int femfct_last_step_info(femfct_ctx* ctx, femfct_step_info* info_host, int32_t batch);
+
+/* host-buffer convenience form of the same call (CSR values on the pattern;
+ * uploads, runs, downloads, synchronises) */
+int femfct_fct_step_host(femfct_ctx* ctx, const double* A_csr_vals, const double* N_csr_vals,
+                         const double* rhs, const double* u_n, double dt, double* u_out,
+                         femfct_step_info* info);
+
+/* ChebSI(vec, M, Md, cheb_iter, lmin, lmax)  helpers.py:143-185 (M = registered mass matrix,
+ * Md = its diagonal). */
+int femfct_chebsi(femfct_ctx* ctx, const double* b_dev, double* y_dev, int32_t cheb_iter,
+                  double lmin, double lmax, int32_t batch);
+/* artificial_diffusion_mat(mat)  helpers.py:206-242: D_ell from K_ell (diagonal included) */
+int femfct_artificial_diffusion(femfct_ctx* ctx, const double* K_ell, double* D_ell, int32_t batch);
+/* y = alpha * Mat * x + beta * y  with an ELL matrix on the registered pattern */
+int femfct_spmv(femfct_ctx* ctx, const double* mat_ell, const double* x_dev, double alpha,
+                double beta, double* y_dev, int32_t batch);
+
+/* ------------------------------------------------ structured-mesh assembly
+ * Device replacements of the dolfin assembly calls on the hot path (helpers.py:87-141). */
+
+/* coordinates of the 6 quadrature points of every triangle, layout
+ * [((cy*n_cells+cx)*2 + type)*6 + q], type 0 = (v0,v1,v3), 1 = (v0,v2,v3); host arrays of
+ * n_cells*n_cells*2*6 doubles.  The host evaluates its wind (a dolfin Expression in the
+ * reference, helpers.py:506-508, 876-878) at these points. */
+int femfct_mesh_quad_points(femfct_ctx* ctx, double* xq_host, double* yq_host);
+/* scale * assemble_sparse(dot(wind, grad(v))*u*dx)  (helpers.py:581,933,1015;
+ * advection_solidbody_FCT_PDECO_finaltime.py:122); wind_q_host[.. *2 + {0,1}] at the points above. */
+int femfct_assemble_convection(femfct_ctx* ctx, const double* wind_q_host, double scale, double* A_ell_dev);
+/* rhs_dk = -(beta*M*c + assemble(p*dot(drift, grad(u))*v*dx)) for `levels` consecutive time levels
+ * (advection_solidbody_FCT_PDECO_finaltime.py:228-236); feed to femfct_chebsi(batch=levels). */
+int femfct_drift_gradient_rhs(femfct_ctx* ctx, const double* c_dev, const double* u_dev, const double* p_dev,
+                              double beta, double bx, double by, double* out_dev, int32_t levels);
+
+/* ------------------------------------------------------ trajectory sweeps
+ * Device-resident time loops.  Trajectories are (num_steps+1)*n doubles, level-major;
+ * batch member b of a trajectory argument starts at b*(num_steps+1)*n.  c_shared != 0: one
+ * control trajectory for the whole batch.  Each call synchronises once at its end (it reads
+ * the per-step solver log) and returns FEMFCT_ERR_NOT_CONVERGED if a low-order solve missed
+ * the tolerance even with max_iters sweeps. */
+
+/* state sweep of the drift-control problem, u level 0 = initial condition (in place):
+ * advection_solidbody_FCT_PDECO_finaltime.py:175-193  (A_u = -eps*Ad + rot_scale*Arot + Adrift1 + Adrift2,
+ * control at level n+1, FCT_alg(A_u,...) == FCT_alg_ref(-A_u,...)) */
+int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
+                             double* u_traj, int32_t num_steps, double dt, double eps, double rot_scale,
+                             double bx, double by, int32_t batch);
+/* adjoint sweep: advection_solidbody_FCT_PDECO_finaltime.py:200-221 (alltime = 0: uhat is n doubles
+ * per batch member, p(T) = uhat - u(T), zero rhs) and advection_solidbody_FCT_PDECO_alltime.py:232-259
+ * (alltime = 1: uhat is a trajectory, p(T) = 0, rhs = assemble((uhat_n - u_n)*v*dx)) */
+int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
+                             const double* u_traj, const double* uhat, double* p_traj, int32_t num_steps,
+                             double dt, double eps, double rot_scale, double bx, double by, int32_t alltime,
+                             int32_t batch);
+/* solver diagnostics of the most recent sweep: info_host[step*batch + b] */
+int femfct_traj_info(femfct_ctx* ctx, femfct_step_info* info_host, int32_t num_steps, int32_t batch);
+
+/* ------------------------------------------------------ optimisation layer
+ * Reductions/updates of the projected-gradient loop kept on the device (only scalars
+ * cross PCIe).  M is the registered mass matrix; results are written to host memory
+ * (these calls synchronise).  batch member b of a trajectory starts at b*(num_steps+1)*n. */
+
+/* L2_norm_sq_Q(phi, num_steps, dt, M)  helpers.py:330-360, phi = a - b (b may be NULL) */
+int femfct_l2_norm_sq_Q(femfct_ctx* ctx, const double* a_dev, const double* b_dev, int32_t num_steps,
+                        double dt, double* out_host, int32_t batch);
+/* L2_norm_sq_Omega(phi, M)  helpers.py:362-381, phi = a - b, one level of n doubles per batch member */
+int femfct_l2_norm_sq_Omega(femfct_ctx* ctx, const double* a_dev, const double* b_dev, double* out_host,
+                            int32_t batch);
+/* cost_functional(var1, var1_target, projected_control, num_steps, dt, M, beta, optim, var2, var2_target)
+ * helpers.py:383-441; finaltime = 0: optim == "alltime" (targets are trajectories),
+ * finaltime = 1: optim == "finaltime" (targets are n doubles per batch member). */
+int femfct_cost_functional(femfct_ctx* ctx, const double* var1, const double* var1_target,
+                           const double* control, int32_t control_shared, int32_t num_steps, double dt,
+                           double beta, int32_t finaltime, const double* var2, const double* var2_target,
+                           double* J_host, int32_t batch);
+/* update_control: out = clip(c + s*d, c_lower, c_upper)  helpers.py:1666-1667 (out may alias c) */
+int femfct_project_control(femfct_ctx* ctx, const double* c_dev, double s, const double* d_dev,
+                           double c_lower, double c_upper, double* out_dev, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMFCT_H */

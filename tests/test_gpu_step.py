@@ -1,0 +1,174 @@
+"""GPU parity tests of the step operator through the C ABI (run with -m gpu).
+
+Bar: float64, relative l2 error < 1e-9 per FCT step against the reference's own
+outputs (golden vectors) -- the north-star tolerance is 1e-6 on whole trajectories.
+"""
+import importlib
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix, diags
+
+from helpers_golden import load, fct_case, fct_case_names, csr_from
+
+pytestmark = pytest.mark.gpu
+
+TOL_STEP = 1e-9
+
+
+@pytest.fixture(scope="module")
+def hp():
+    mod = importlib.import_module("fem-fct-pdeco_amd")
+    mod.fct_helpers.VERBOSE = False
+    return mod
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("name", fct_case_names())
+def test_fct_step_vs_reference_golden(hp, name):
+    c = fct_case(load("fct_cases.npz"), name)
+    info = {}
+    u = hp.FCT_alg_ref(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"], None,
+                       non_flux_mat=c["N"], info=info)
+    assert rel(u, c["u_np1"]) < TOL_STEP, (name, rel(u, c["u_np1"]), info)
+    assert bool(info["flags"] & hp.FLAG_MMATRIX_ROWSUM) == c["mmatrix_failed"]
+    assert not (info["flags"] & hp.FLAG_SOLVER_BUDGET)
+    assert info["solver_resid"] <= 1e-13
+
+
+def test_fct_step_inputs_not_mutated_and_new_array(hp):
+    c = fct_case(load("fct_cases.npz"), "driftctl_N11")
+    A0, u0, r0 = c["A"].copy(), c["u_n"].copy(), c["rhs"].copy()
+    u = hp.FCT_alg_ref(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"], None)
+    assert u is not c["u_n"]
+    assert np.array_equal(c["u_n"], u0) and np.array_equal(c["rhs"], r0)
+    assert (c["A"] != A0).nnz == 0
+
+
+def test_fct_step_accepts_lil_and_scalar_rhs(hp):
+    c = fct_case(load("fct_cases.npz"), "rot_N11")
+    u = hp.FCT_alg_ref(c["A"].tolil(), 0, c["u_n"], c["dt"], c["n"], c["M"].tolil(), c["ML"].tolil(), None)
+    assert rel(u, c["u_np1"]) < TOL_STEP
+
+
+def test_old_sign_convention(hp):
+    z = load("fct_old_sign.npz")
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler, row_lump_diag
+    a1, a2, nc = z["geom"]
+    asm = P1Assembler(SquareMesh(a1, a2, int(nc)))
+    M = asm.mass()
+    n = M.shape[0]
+    ML = diags(row_lump_diag(M)).tocsr()
+    u = hp.FCT_alg(csr_from(z, "A", n), z["rhs"], z["u_n"], float(z["dt"]), n, M, ML, None,
+                   source_mat=csr_from(z, "S", n))
+    assert rel(u, z["u_old"]) < TOL_STEP
+
+
+def test_properties_mass_and_bounds(hp):
+    """Scheme invariants (SURVEY 8d parity gate): with zero-flux operator the step conserves
+    sum_i m_i u_i, and u^{n+1} stays within the neighbourhood bounds of u_Low."""
+    from oracle import fct as ofct
+    c = fct_case(load("fct_cases.npz"), "rot_N41")
+    u = hp.FCT_alg_ref(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"], None)
+    info = {}
+    ofct.fct_step(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"], None, info=info)
+    pat = ofct.Pattern(c["M"])
+    ul = info["u_low"]
+    umax = pat.rowmax(ul[pat.indices])
+    umin = pat.rowmin(ul[pat.indices])
+    assert np.all(u <= umax + 1e-14) and np.all(u >= umin - 1e-14)
+    # rotation wind has w.n = 0 on the boundary of [-1,1]^2 only approximately at corners; compare
+    # mass change with the oracle's instead of with zero
+    mass_gpu = c["ml"] @ u
+    mass_ref = c["ml"] @ c["u_np1"]
+    assert abs(mass_gpu - mass_ref) <= 1e-12 * abs(mass_ref)
+
+
+def test_small_kernels(hp):
+    z = load("kernels.npz")
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    a1, a2, nc = z["geom"]
+    asm = P1Assembler(SquareMesh(a1, a2, int(nc)))
+    M = asm.mass()
+    n = M.shape[0]
+    y = hp.ChebSI(z["cheb_b"], M, M.diagonal(), 20, 0.5, 2)
+    assert rel(y, z["cheb_y"]) < 1e-13
+    with pytest.raises(ValueError):
+        hp.ChebSI(z["cheb_b"], M, 2 * M.diagonal())
+    K = csr_from(z, "K", n)
+    D = hp.artificial_diffusion_mat(K)
+    Dref = csr_from(z, "D", n)
+    assert abs(csr_matrix(D) - Dref).max() < 1e-15
+    assert np.max(np.abs(hp.row_lump(M, n).diagonal() - z["ml"])) < 1e-17
+    Nt, dt, beta = int(z["Nt"]), float(z["dt"]), float(z["beta"])
+    assert abs(hp.L2_norm_sq_Q(z["phi"], Nt, dt, M) - z["L2Q"]) < 1e-12 * abs(z["L2Q"])
+    assert abs(hp.L2_norm_sq_Omega(z["phi"][:n], M) - z["L2Omega"]) < 1e-12 * abs(z["L2Omega"])
+    J = hp.cost_functional
+    assert abs(J(z["phi"], z["tgt"], z["ctl"], Nt, dt, M, beta, "alltime") - z["J_alltime_1"]) < 1e-12 * abs(z["J_alltime_1"])
+    assert abs(J(z["phi"], z["tgt"], z["ctl"], Nt, dt, M, beta, "alltime", var2=z["phi2"], var2_target=z["tgt2"])
+               - z["J_alltime_2"]) < 1e-12 * abs(z["J_alltime_2"])
+    assert abs(J(z["phi"], z["tgt"][:n], z["ctl"], Nt, dt, M, beta, "finaltime") - z["J_finaltime_1"]) < 1e-12 * abs(z["J_finaltime_1"])
+    assert abs(J(z["phi"], z["tgt"][:n], z["ctl"], Nt, dt, M, beta, "finaltime", var2=z["phi2"], var2_target=z["tgt2"][:n])
+               - z["J_finaltime_2"]) < 1e-12 * abs(z["J_finaltime_2"])
+    with pytest.raises(ValueError):
+        J(z["phi"], z["tgt"], z["ctl"], Nt, dt, M, beta, "sometime")
+    with pytest.raises(ValueError):
+        hp.L2_norm_sq_Q(z["phi"][:-1], Nt, dt, M)
+
+
+def test_error_paths(hp):
+    c = fct_case(load("fct_cases.npz"), "rot_N5")
+    bad = c["A"].tolil()
+    bad[0, c["n"] - 1] = 1.0  # outside the mesh pattern
+    with pytest.raises(ValueError):
+        hp.FCT_alg_ref(bad, c["rhs"], c["u_n"], c["dt"], c["n"], c["M"], c["ML"], None)
+    with pytest.raises(ValueError):
+        hp.FCT_alg_ref(c["A"], c["rhs"], c["u_n"], c["dt"], c["n"] + 1, c["M"], c["ML"], None)
+    ctx = hp.Context(0)
+    with pytest.raises(ValueError):
+        ctx.set_pattern_csr([0, 1, 2], [1, 0])  # no diagonal
+    with pytest.raises(ValueError):
+        ctx.set_pattern_csr([0, 2, 3], [0, 1, 1])  # not symmetric
+    ctx.close()
+
+
+def test_batched_step_matches_single(hp):
+    """B systems in one launch sequence == B separate calls (bitwise)."""
+    names = ["rot_N41", "rotdrift22_N41", "driftctl_N41"]
+    z = load("fct_cases.npz")
+    cs = [fct_case(z, k) for k in names]
+    n = cs[0]["n"]
+    ctx = hp.Context(0)
+    M = cs[0]["M"]
+    M.sort_indices()
+    ctx.set_pattern_csr(M.indptr, M.indices)
+    ctx.set_mass(M.data, cs[0]["ml"])
+    W = ctx.W
+    A = ctx.empty(3 * W * n)
+    one = ctx.empty(W * n)
+    u_in = ctx.empty(3 * n)
+    u_out = ctx.empty(3 * n)
+    for b, c in enumerate(cs):
+        Ab = c["A"].copy()
+        Ab.sort_indices()
+        ctx.csr_to_ell(Ab.data, one)
+        A.copy_from(one, W * n, dst_off=b * W * n)
+    u_in.upload(np.concatenate([c["u_n"] for c in cs]))
+    ctx.fct_step(A, u_in, cs[0]["dt"], u_out, batch=3)
+    out = u_out.download().reshape(3, n)
+    infos = ctx.last_step_info(3)
+    for b, c in enumerate(cs):
+        assert rel(out[b], c["u_np1"]) < TOL_STEP
+        single = hp.FCT_alg_ref(c["A"], c["rhs"], c["u_n"], c["dt"], n, c["M"], c["ML"], None)
+        assert np.array_equal(single, out[b])
+        assert not (infos[b]["flags"] & hp.FLAG_SOLVER_BUDGET)
+    # graphs on/off give identical bits
+    ctx.set_graphs(False)
+    ctx.fct_step(A, u_in, cs[0]["dt"], u_out, batch=3)
+    assert np.array_equal(u_out.download().reshape(3, n), out)
+    ctx.close()
