@@ -79,6 +79,21 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     ctx->n = 0; ctx->W = 0; ctx->nnz_csr = 0; ctx->ws_batch = 0; ctx->have_mass = false; ctx->structured = false;
 }
 
+void femfct_prof_begin(femfct_ctx* ctx, int cls) {
+    if (!ctx->prof_on) return;
+    femfct_ctx::ProfRec r;
+    r.cls = cls;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, ctx->stream);
+    ctx->prof.push_back(r);
+}
+
+void femfct_prof_end(femfct_ctx* ctx) {
+    if (!ctx->prof_on || ctx->prof.empty()) return;
+    hipEventRecord(ctx->prof.back().b, ctx->stream);
+}
+
 void femfct_drop_graphs(femfct_ctx* ctx) {
     for (auto& kv : ctx->graphs) hipGraphExecDestroy(kv.second);
     ctx->graphs.clear();
@@ -207,6 +222,34 @@ int femfct_set_graphs(femfct_ctx* ctx, int enable) {
     ARG_TRY(ctx, ctx, "null ctx");
     ctx->use_graphs = enable != 0;
     if (!enable) femfct_drop_graphs(ctx);
+    return FEMFCT_OK;
+}
+
+// per-kernel timing with HIP events on the ctx stream.  Profiling forces eager launches
+// (graphs off) while enabled.
+int femfct_set_profiling(femfct_ctx* ctx, int enable) {
+    ARG_TRY(ctx, ctx, "null ctx");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    ctx->prof.clear();
+    ctx->prof_on = enable != 0;
+    return FEMFCT_OK;
+}
+
+int femfct_profile_report(femfct_ctx* ctx, double* total_ms_host, int32_t* launches_host, int32_t n_classes) {
+    ARG_TRY(ctx, ctx && total_ms_host && launches_host && n_classes >= KC_COUNT, "need >= 8 classes");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_classes; ++k) { total_ms_host[k] = 0.0; launches_host[k] = 0; }
+    for (auto& r : ctx->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            total_ms_host[r.cls] += ms;
+            launches_host[r.cls] += 1;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    ctx->prof.clear();
     return FEMFCT_OK;
 }
 

@@ -83,6 +83,12 @@ struct femfct_ctx {
     std::vector<StepCtl> h_log;                                     // last trajectory's log
     int32_t log_steps = 0, log_batch = 0;
 
+    // optional per-kernel HIP-event timing (femfct_set_profiling): event pairs recorded on the
+    // ctx stream around every launch of the step sequence, resolved by femfct_profile_report
+    bool prof_on = false;
+    struct ProfRec { int cls; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
+
     // scratch for reductions (kernels_pgd.hip)
     double* d_scratch = nullptr;
     size_t scratch_count = 0;
@@ -116,6 +122,11 @@ static inline uint64_t key_bits(int32_t v) { return (uint64_t)(int64_t)v; }
 template <class F>
 int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue);
 
+// kernel classes for profiling
+enum { KC_BUILD_LOW = 0, KC_JACOBI, KC_DUDT_RHS, KC_CHEB, KC_FLUX, KC_LIMIT, KC_ASSEMBLE, KC_OTHER, KC_COUNT };
+void femfct_prof_begin(femfct_ctx* ctx, int cls);
+void femfct_prof_end(femfct_ctx* ctx);
+
 // kernel launchers (kernels_step.hip) -----------------------------------------
 struct LaunchGeom { dim3 grid; dim3 block; };
 LaunchGeom femfct_geom(const femfct_ctx* ctx, int32_t batch);
@@ -126,7 +137,7 @@ int femfct_enqueue_step(femfct_ctx* ctx, const double* A, const double* N, int32
 
 template <class F>
 int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue) {
-    if (!ctx->use_graphs) return enqueue();
+    if (!ctx->use_graphs || ctx->prof_on) return enqueue();
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
         if (ctx->graphs.size() > 64) femfct_drop_graphs(ctx);

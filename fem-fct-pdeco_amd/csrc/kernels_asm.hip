@@ -241,8 +241,10 @@ int femfct_enqueue_mesh_constants(femfct_ctx* ctx) {
 int femfct_enqueue_ops_solidbody(femfct_ctx* ctx, const double* Arot, VecRef c_ref, int64_t c_bstride, double eps,
                                  double sigma, double rot_scale, double bx, double by, double* A, int32_t batch) {
     LaunchGeom g = femfct_geom(ctx, batch);
+    femfct_prof_begin(ctx, KC_ASSEMBLE);
     hipLaunchKernelGGL(k_ops_solidbody, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->N, ctx->n_cells, ctx->h,
                        ctx->d_d2v, ctx->d_cols, ctx->d_Ad, Arot, c_ref, c_bstride, eps, sigma, rot_scale, bx, by, A);
+    femfct_prof_end(ctx);
     return FEMFCT_OK;
 }
 

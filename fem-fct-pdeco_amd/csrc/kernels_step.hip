@@ -32,8 +32,8 @@ __device__ __forceinline__ const double* sel(const StepCtl* ctl, const double* x
 // ---------------------------------------------------------------------------
 // k_build_low: artificial diffusion + low-order operator + rhs (helpers.py:1769-1780)
 // ---------------------------------------------------------------------------
-template <int WT>
-__global__ void k_build_low(int n, int Wrt, const int32_t* __restrict__ cols,
+template <int WT, int BS>
+__global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, const int32_t* __restrict__ cols,
                             const uint8_t* __restrict__ tslot, const double* __restrict__ A_,
                             const double* __restrict__ N_, int nshared, VecRef rhs_ref, VecRef u_ref,
                             int64_t rhs_bstride, int64_t u_bstride,
@@ -107,8 +107,8 @@ __global__ void k_build_low(int n, int Wrt, const int32_t* __restrict__ cols,
 // Since x_new - x_old = Dg^-1 r(x_old), every sweep also yields the true residual
 // of its input iterate; convergence is decided on the device from those.
 // ---------------------------------------------------------------------------
-template <int WT>
-__global__ void k_jacobi(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ L_,
+template <int WT, int BS>
+__global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ L_,
                          const double* __restrict__ b_, double* __restrict__ xa_, double* __restrict__ xb_,
                          double* __restrict__ part, StepCtl* __restrict__ ctl_, int sweep, double rel_tol) {
     __shared__ double smem[32];
@@ -183,8 +183,8 @@ __device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, i
 // k_dudt_rhs: r = rhs - A u_L (helpers.py:1814) fused with Chebyshev iterate 1
 // (y_1 = omega_1 * r / (1.25 diag M), helpers.py:175-182 with y_0 = y_-1 = 0).
 // ---------------------------------------------------------------------------
-template <int WT>
-__global__ void k_dudt_rhs(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ A_,
+template <int WT, int BS>
+__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ A_,
                            VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
                            const double* __restrict__ xa_, const double* __restrict__ xb_,
                            double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
@@ -226,8 +226,8 @@ __global__ void k_dudt_rhs(int n, int Wrt, const int32_t* __restrict__ cols, con
 // k_cheb: one Chebyshev semi-iteration step (helpers.py:175-184)
 //   r = b - M y_mid ; z = r / Md ; y_new = omega (z + y_mid - y_old) + y_old
 // ---------------------------------------------------------------------------
-template <int WT>
-__global__ void k_cheb(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
+template <int WT, int BS>
+__global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
                        const double* __restrict__ b_, const double* __restrict__ ymid_,
                        const double* __restrict__ yold_, double* __restrict__ ynew_, double omega,
                        double md_scale) {
@@ -259,8 +259,8 @@ __global__ void k_cheb(int n, int Wrt, const int32_t* __restrict__ cols, const d
 // ---------------------------------------------------------------------------
 // k_flux: raw antidiffusive fluxes + Zalesak P/Q/R (helpers.py:1818-1851)
 // ---------------------------------------------------------------------------
-template <int WT>
-__global__ void k_flux(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
+template <int WT, int BS>
+__global__ void __launch_bounds__(BS) k_flux(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
                        const double* __restrict__ D_, const double* __restrict__ ulow_,
                        const double* __restrict__ du_, const double* __restrict__ ml, double dt,
                        double* __restrict__ F_, double* __restrict__ rp_, double* __restrict__ rm_) {
@@ -299,8 +299,8 @@ __global__ void k_flux(int n, int Wrt, const int32_t* __restrict__ cols, const d
 // ---------------------------------------------------------------------------
 // k_limit: alpha_ij, limited flux sum and explicit correction (helpers.py:1860-1870)
 // ---------------------------------------------------------------------------
-template <int WT>
-__global__ void k_limit(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ F_,
+template <int WT, int BS>
+__global__ void __launch_bounds__(BS) k_limit(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ F_,
                         const double* __restrict__ rp_, const double* __restrict__ rm_,
                         const double* __restrict__ ulow_, const double* __restrict__ ml, double dt,
                         VecRef out_ref, int64_t out_bstride) {
@@ -393,10 +393,19 @@ static void cheb_omegas(int iters, double lmin, double lmax, std::vector<double>
     }
 }
 
-#define LAUNCH_W(kern, geom, stream, ...)                                                  \
-    do {                                                                                   \
-        if (ctx->W == 7) hipLaunchKernelGGL((kern<7>), geom.grid, geom.block, 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((kern<0>), geom.grid, geom.block, 0, stream, __VA_ARGS__);  \
+// BS is a template parameter (64 for small meshes, 256 otherwise) so that profiles list the
+// latency-regime and the bandwidth-regime instances of a kernel under different names.
+#define LAUNCH_W(cls, kern, geom, stream, ...)                                                          \
+    do {                                                                                                \
+        femfct_prof_begin(ctx, cls);                                                                    \
+        if (ctx->W == 7) {                                                                              \
+            if (geom.block.x == 64) hipLaunchKernelGGL((kern<7, 64>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
+            else hipLaunchKernelGGL((kern<7, 256>), geom.grid, geom.block, 0, stream, __VA_ARGS__);      \
+        } else {                                                                                        \
+            if (geom.block.x == 64) hipLaunchKernelGGL((kern<0, 64>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
+            else hipLaunchKernelGGL((kern<0, 256>), geom.grid, geom.block, 0, stream, __VA_ARGS__);      \
+        }                                                                                               \
+        femfct_prof_end(ctx);                                                                           \
     } while (0)
 
 int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int iters, double lmin, double lmax,
@@ -413,7 +422,7 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
         const double* mid = (k >= 2) ? buf[(k - 1) % 3] : nullptr;
         const double* old = (k >= 3) ? buf[(k - 2) % 3] : nullptr;
         double* out = (k == iters) ? y_out : buf[k % 3];
-        LAUNCH_W(k_cheb, g, ctx->stream, n, W, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale);
+        LAUNCH_W(KC_CHEB, k_cheb, g, ctx->stream, n, W, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale);
     }
     return FEMFCT_OK;
 }
@@ -425,19 +434,19 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     LaunchGeom g = femfct_geom(ctx, batch);
     hipStream_t st = ctx->stream;
     int n = ctx->n, W = ctx->W;
-    LAUNCH_W(k_build_low, g, st, n, W, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n, rhs_bstride,
+    LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n, rhs_bstride,
              u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
     for (int s = 0; s < budget; ++s)
-        LAUNCH_W(k_jacobi, g, st, n, W, ctx->d_cols, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, ctx->d_part,
+        LAUNCH_W(KC_JACOBI, k_jacobi, g, st, n, W, ctx->d_cols, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, ctx->d_part,
                  ctx->d_ctl, s, ctx->rel_tol);
     // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
     double* ulow = ctx->d_b;
-    LAUNCH_W(k_dudt_rhs, g, st, n, W, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
+    LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
              ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, budget, ctx->rel_tol, 1.25, 1.0);
     femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
-    LAUNCH_W(k_flux, g, st, n, W, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt, ctx->d_F,
+    LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt, ctx->d_F,
              ctx->d_rp, ctx->d_rm);
-    LAUNCH_W(k_limit, g, st, n, W, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt, u_out,
+    LAUNCH_W(KC_LIMIT, k_limit, g, st, n, W, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt, u_out,
              out_bstride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));

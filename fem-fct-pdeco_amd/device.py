@@ -118,6 +118,18 @@ class Context:
     def set_graphs(self, enable: bool):
         check(self.handle, lib.femfct_set_graphs(self.handle, int(bool(enable))))
 
+    KERNEL_CLASSES = ("build_low", "jacobi", "dudt_rhs", "cheb", "flux", "limit", "assemble", "other")
+
+    def set_profiling(self, enable: bool):
+        check(self.handle, lib.femfct_set_profiling(self.handle, int(bool(enable))))
+
+    def profile_report(self):
+        """{class: (total_ms, launches)} of the kernels run since profiling was enabled / last report."""
+        ms = np.zeros(8)
+        cnt = np.zeros(8, dtype=np.int32)
+        check(self.handle, lib.femfct_profile_report(self.handle, _host_ptr(ms), _host_ptr(cnt), 8))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     def synchronize(self):
         check(self.handle, lib.femfct_synchronize(self.handle))
 

@@ -80,6 +80,12 @@ void*       femfct_stream(femfct_ctx* ctx);                 /* hipStream_t */
 int         femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters);
 int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay of the step sequence (default on) */
 
+/* Per-kernel timing with HIP events recorded on the ctx stream around every kernel of the step
+ * sequence (used by bench.py for the roofline figures).  While enabled, launches are eager.
+ * Classes: 0 build_low, 1 jacobi sweep, 2 dudt_rhs, 3 chebyshev step, 4 flux, 5 limit, 6 assembly, 7 other. */
+int femfct_set_profiling(femfct_ctx* ctx, int enable);
+int femfct_profile_report(femfct_ctx* ctx, double* total_ms_host, int32_t* launches_host, int32_t n_classes);
+
 /* device memory helpers (so that a ctypes-only host needs no other GPU library) */
 int femfct_malloc(femfct_ctx* ctx, void** dev_ptr, size_t bytes);
 int femfct_free(femfct_ctx* ctx, void* dev_ptr);
