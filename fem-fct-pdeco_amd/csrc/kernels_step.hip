@@ -22,6 +22,7 @@
 #include "device_utils.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -375,6 +376,7 @@ __global__ void k_spmv(int n, int W, const int32_t* __restrict__ cols, const dou
 // ---------------------------------------------------------------------------
 LaunchGeom femfct_geom(const femfct_ctx* ctx, int32_t batch) {
     int bs = (ctx->n <= 65536) ? 64 : 256;
+    if (const char* e = getenv("FEMFCT_BLOCK")) { int v = atoi(e); if (v == 64 || v == 256) bs = v; }  // tuning knob
     int64_t g = ((int64_t)ctx->n + bs - 1) / bs;
     if (g > FEMFCT_MAX_PARTIALS) g = FEMFCT_MAX_PARTIALS;
     if (g < 1) g = 1;

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Run bench.py with the given arguments and print a one-line summary (tuning helper)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + sys.argv[1:], capture_output=True, text=True)
+line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+if not line:
+    print(out.stdout[-2000:], out.stderr[-4000:])
+    sys.exit(1)
+d = json.loads(line[-1])
+tag = os.environ.get("TAG", "")
+msg = f"{tag} value={d['value']:.1f} {d['unit']} ms_per_step={d['ms_per_step']:.2f} sweeps={d['config'].get('jacobi_sweeps_max')}"
+if "roofline" in d:
+    msg += " roofline: " + " ".join(f"{k}={v['achieved_GBps']:.0f}GB/s" for k, v in d["roofline"]["kernels"].items())
+print(msg)
