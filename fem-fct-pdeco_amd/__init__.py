@@ -18,6 +18,11 @@ from .fct_helpers import (  # noqa: F401
     find_node_neighbours, L2_norm_sq_Q, L2_norm_sq_Omega, cost_functional,
     reorder_vector_to_dof, reorder_vector_from_dof, reorder_vector_to_dof_time,
     reorder_vector_from_dof_time, set_device)
-from . import fct_helpers  # noqa: F401
+from .systems import (  # noqa: F401
+    solve_nonlinear_equation, solve_adjoint_nonlinear_equation, solve_schnak_system,
+    solve_adjoint_schnak_system, solve_chtxs_system, solve_adjoint_chtxs_system,
+    get_schnak_sys_params, get_nonlinear_eqns_params, get_chtxs_sys_params,
+    schnak_sys_IC, nonlinear_equation_IC, chtxs_sys_IC)
+from . import fct_helpers, systems, solvers  # noqa: F401
 
 __version__ = "0.1.0"

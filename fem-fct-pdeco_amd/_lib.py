@@ -101,6 +101,17 @@ SIGNATURES = {
     "femfct_solidbody_forward": (C.c_int, [_p, _p, _p, _i, _p, _i, _d, _d, _d, _d, _d, _i]),
     "femfct_solidbody_adjoint": (C.c_int, [_p, _p, _p, _i, _p, _p, _p, _i, _d, _d, _d, _d, _d, _i, _i]),
     "femfct_traj_info": (C.c_int, [_p, C.POINTER(StepInfo), _i, _i]),
+    "femfct_ell_transpose": (C.c_int, [_p, _p, _p]),
+    "femfct_axpby": (C.c_int, [_p, C.c_int64, _d, _p, _d, _p, _p]),
+    "femfct_set_krylov": (C.c_int, [_p, _d, _i]),
+    "femfct_bicgstab": (C.c_int, [_p, _p, _i, _p, _p, _p, _i, C.POINTER(StepInfo)]),
+    "femfct_nonlinear_forward": (C.c_int, [_p, _p, _p, _p, _i, _d, _d, _i]),
+    "femfct_nonlinear_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _i, _d, _d, _i]),
+    "femfct_schnak_forward": (C.c_int, [_p, _p, _p, _p, _p, _i, _d, _p, _d, _i]),
+    "femfct_schnak_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _p, _i]),
+    "femfct_chtxs_forward": (C.c_int, [_p, _p, _p, _p, _i, _d, _p, _d, _i]),
+    "femfct_chtxs_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _p, _d, _i, _i]),
+    "femfct_traj_krylov_info": (C.c_int, [_p, C.POINTER(StepInfo), _i, _i]),
     "femfct_l2_norm_sq_Q": (C.c_int, [_p, _p, _p, _i, _d, _p, _i]),
     "femfct_l2_norm_sq_Omega": (C.c_int, [_p, _p, _p, _p, _i]),
     "femfct_cost_functional": (C.c_int, [_p, _p, _p, _p, _i, _i, _d, _d, _i, _p, _p, _p, _i]),

@@ -76,6 +76,11 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_trA); dev_free(&ctx->d_trN); dev_free(&ctx->d_trRhs); dev_free(&ctx->d_level); dev_free(&ctx->d_log);
     ctx->tr_batch = 0; ctx->tr_steps = 0;
     dev_free(&ctx->d_scratch); ctx->scratch_count = 0;
+    dev_free(&ctx->d_kry); dev_free(&ctx->d_kry_part);
+    if (ctx->d_kry_ctl) { hipFree(ctx->d_kry_ctl); ctx->d_kry_ctl = nullptr; }
+    if (ctx->d_klog) { hipFree(ctx->d_klog); ctx->d_klog = nullptr; }
+    ctx->kry_batch = 0;
+    dev_free(&ctx->d_trMat); dev_free(&ctx->d_trBase); dev_free(&ctx->d_trBase2); dev_free(&ctx->d_trRhs2); dev_free(&ctx->d_trTmp);
     ctx->n = 0; ctx->W = 0; ctx->nnz_csr = 0; ctx->ws_batch = 0; ctx->have_mass = false; ctx->structured = false;
 }
 

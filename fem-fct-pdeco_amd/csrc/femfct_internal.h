@@ -89,6 +89,20 @@ struct femfct_ctx {
     struct ProfRec { int cls; hipEvent_t a, b; };
     std::vector<ProfRec> prof;
 
+    // Krylov workspace / settings (kernels_krylov.hip)
+    int32_t kry_batch = 0;
+    double* d_kry = nullptr;        // 9 vectors [9][kry_batch*n]
+    double* d_kry_part = nullptr;
+    void* d_kry_ctl = nullptr;      // KrylovCtl[kry_batch]
+    double kry_tol = 1e-13;
+    int kry_max_iters = 2000;
+    int kry_budget = 40;            // adaptive
+    void* d_klog = nullptr;         // KrylovCtl[tr_steps * tr_batch]
+    std::vector<char> h_klog;
+    // extra trajectory operators
+    double *d_trMat = nullptr, *d_trBase = nullptr, *d_trBase2 = nullptr;  // [B*W*n], [W*n], [W*n]
+    double *d_trRhs2 = nullptr, *d_trTmp = nullptr;                        // [B*n]
+
     // scratch for reductions (kernels_pgd.hip)
     double* d_scratch = nullptr;
     size_t scratch_count = 0;

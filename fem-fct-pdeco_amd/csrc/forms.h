@@ -1,0 +1,54 @@
+// Argument structs of the quadrature-form kernels (kernels_forms.hip) and the Krylov solver.
+#pragma once
+
+#include "device_utils.h"
+
+struct femfct_ctx;
+
+struct MeshArgs {
+    int n, N, nc;
+    double h;
+    const int32_t* d2v;
+    const int32_t* cols;
+    const double* M;
+    const double* Ad;
+};
+
+// out = alpha*M + gamma*base + beta * int f1 f2 phi_i phi_j
+struct WMassSpec {
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+    const double* base = nullptr;   // constant ELL matrix (shared by the batch)
+    VecRef f1{nullptr, nullptr, 0, 0}, f2{nullptr, nullptr, 0, 0};
+    int64_t f1_bs = 0, f2_bs = 0;
+};
+
+// out_i = s0*(M mx)_i + s1 * int (k0 + k1*p1 + k2*q1*q2*q3) phi_i + s2*(da_i - db_i)
+struct LoadSpec {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, k0 = 0.0, k1 = 0.0, k2 = 0.0;
+    VecRef mx{nullptr, nullptr, 0, 0}, p1{nullptr, nullptr, 0, 0}, q1{nullptr, nullptr, 0, 0},
+        q2{nullptr, nullptr, 0, 0}, q3{nullptr, nullptr, 0, 0}, da{nullptr, nullptr, 0, 0},
+        db{nullptr, nullptr, 0, 0};
+    int64_t mx_bs = 0, p1_bs = 0, q1_bs = 0, q2_bs = 0, q3_bs = 0, da_bs = 0, db_bs = 0;
+};
+
+MeshArgs femfct_mesh_args(const femfct_ctx* ctx);
+int femfct_enqueue_weighted_mass(femfct_ctx* ctx, const WMassSpec& sp, double* out, int32_t batch);
+int femfct_enqueue_load(femfct_ctx* ctx, const LoadSpec& sp, double* out, int32_t batch);
+int femfct_enqueue_chtxs_matrix(femfct_ctx* ctx, int adjoint, VecRef u, int64_t u_bs, VecRef v, int64_t v_bs,
+                                double Dm, double chi, double eta, double* out, int32_t batch);
+int femfct_enqueue_chtxs_rhs_q(femfct_ctx* ctx, VecRef u, int64_t u_bs, VecRef p, int64_t p_bs, double chi, double eta,
+                               VecRef da, int64_t da_bs, VecRef db, int64_t db_bs, double* out, int32_t batch);
+
+// Jacobi-preconditioned BiCGStab for the non-FCT implicit solves (kernels_krylov.hip)
+struct KrylovCtl {
+    int32_t flags;       // 1: breakdown, FEMFCT_FLAG_SOLVER_BUDGET: budget exhausted
+    int32_t iters;
+    int32_t done;
+    int32_t pad;
+    double resid;        // ||r||_inf / ||b||_inf
+    double bnorm;
+    double rho2[2];      // rho of iteration it at [it & 1] (two slots: no same-kernel read/write)
+    double alpha, omega;
+};
+int femfct_enqueue_bicgstab(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
+                            int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget);

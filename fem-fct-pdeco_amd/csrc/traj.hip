@@ -11,6 +11,8 @@
 //              /root/reference/advection_solidbody_FCT_PDECO_alltime.py:232-259
 #include "femfct_internal.h"
 #include "device_utils.h"
+#include "forms.h"
+#include "traj_common.h"
 
 #include <algorithm>
 
@@ -29,9 +31,12 @@ namespace {
 
 // end of a step: log the solver control blocks, then move the level counter
 __global__ void k_step_end(int32_t* level, int delta, const StepCtl* __restrict__ ctl, StepCtl* __restrict__ log,
-                           int batch) {
+                           const KrylovCtl* __restrict__ kctl, KrylovCtl* __restrict__ klog, int batch) {
     int ord = level[1];
-    for (int b = threadIdx.x; b < batch; b += blockDim.x) log[(int64_t)ord * batch + b] = ctl[b];
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+        log[(int64_t)ord * batch + b] = ctl[b];
+        if (kctl) klog[(int64_t)ord * batch + b] = kctl[b];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         level[0] += delta;
@@ -39,7 +44,15 @@ __global__ void k_step_end(int32_t* level, int delta, const StepCtl* __restrict_
     }
 }
 
-int ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps) {
+}  // namespace
+
+int femfct_enqueue_step_end(femfct_ctx* ctx, int delta, int32_t batch, bool with_krylov) {
+    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, ctx->d_level, delta, ctx->d_ctl, ctx->d_log,
+                       with_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr, (KrylovCtl*)ctx->d_klog, batch);
+    return FEMFCT_OK;
+}
+
+int femfct_ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps) {
     int rc = femfct_ensure_workspace(ctx, batch);
     if (rc != FEMFCT_OK) return rc;
     if (batch > ctx->tr_batch) {
@@ -52,6 +65,15 @@ int ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trA, sizeof(double) * nm));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trN, sizeof(double) * nm));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trRhs, sizeof(double) * nv));
+        for (double** q : {&ctx->d_trMat, &ctx->d_trBase, &ctx->d_trBase2, &ctx->d_trRhs2, &ctx->d_trTmp}) {
+            if (*q) hipFree(*q);
+            *q = nullptr;
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trMat, sizeof(double) * nm));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trBase, sizeof(double) * ctx->W * ctx->n));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trBase2, sizeof(double) * ctx->W * ctx->n));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trRhs2, sizeof(double) * nv));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trTmp, sizeof(double) * nv));
         if (ctx->d_log) hipFree(ctx->d_log);
         ctx->d_log = nullptr;
         ctx->tr_steps = 0;
@@ -63,51 +85,13 @@ int ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps) {
         if (ctx->d_log) hipFree(ctx->d_log);
         ctx->d_log = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_log, sizeof(StepCtl) * (size_t)steps * ctx->tr_batch));
+        if (ctx->d_klog) hipFree(ctx->d_klog);
+        ctx->d_klog = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_klog, sizeof(KrylovCtl) * (size_t)steps * ctx->tr_batch));
         ctx->tr_steps = steps;
     }
     return FEMFCT_OK;
 }
-
-// Replays `step` num_steps times, then inspects the per-step solver log; if the
-// sweep budget was too small anywhere the whole sweep is repeated with a larger one.
-template <class Begin, class Step>
-int run_sweep(femfct_ctx* ctx, int32_t num_steps, int32_t batch, int level0, Begin&& begin, Step&& step) {
-    for (int attempt = 0;; ++attempt) {
-        const int budget = femfct_round_budget(ctx, ctx->sweep_budget);
-        int rc = begin();
-        if (rc != FEMFCT_OK) return rc;
-        int32_t init[2] = {level0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_level, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-        for (int32_t k = 0; k < num_steps; ++k) {
-            rc = step(budget);
-            if (rc != FEMFCT_OK) return rc;
-        }
-        ctx->h_log.resize((size_t)num_steps * batch);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_log.data(), ctx->d_log, sizeof(StepCtl) * ctx->h_log.size(),
-                                    hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->log_steps = num_steps;
-        ctx->log_batch = batch;
-        int worst = 0;
-        bool short_budget = false;
-        double worst_res = 0.0;
-        for (const StepCtl& c : ctx->h_log) {
-            worst = std::max(worst, c.iters);
-            if (c.flags & FEMFCT_FLAG_SOLVER_BUDGET) { short_budget = true; worst_res = std::max(worst_res, c.resid); }
-        }
-        if (!short_budget) {
-            ctx->sweep_budget = std::min(ctx->max_iters, std::max(8, worst + worst / 4 + 4));
-            return FEMFCT_OK;
-        }
-        if (budget >= ctx->max_iters)
-            return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
-                               "low-order solve: residual %.3e after %d sweeps (tol %.1e)", worst_res, budget,
-                               ctx->rel_tol);
-        ctx->sweep_budget = std::min(ctx->max_iters, budget * 2);
-    }
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -117,13 +101,13 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
     ARG_TRY(ctx, c_traj && u_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
     ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
-    int rc = ensure_traj_ws(ctx, batch, num_steps);
+    int rc = femfct_ensure_traj_ws(ctx, batch, num_steps);
     if (rc != FEMFCT_OK) return rc;
     const int64_t n = ctx->n, tstride = (int64_t)(num_steps + 1) * n;
     const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;  // any valid ELL array; multiplied by 0
     int32_t* lv = ctx->d_level;
     auto begin = [&]() { return FEMFCT_OK; };
-    auto step = [&](int budget) {
+    auto step = [&](int budget, int) {
         femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
                                  key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
@@ -135,11 +119,11 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
                                             make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
                                             tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
-            hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, lv, 1, ctx->d_ctl, ctx->d_log, batch);
+            femfct_enqueue_step_end(ctx, 1, batch, false);
             return FEMFCT_OK;
         });
     };
-    return run_sweep(ctx, num_steps, batch, 0, begin, step);
+    return femfct_run_sweep(ctx, num_steps, batch, 0, false, begin, step);
 }
 
 int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
@@ -148,7 +132,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
     ARG_TRY(ctx, c_traj && u_traj && uhat && p_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
     ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
-    int rc = ensure_traj_ws(ctx, batch, num_steps);
+    int rc = femfct_ensure_traj_ws(ctx, batch, num_steps);
     if (rc != FEMFCT_OK) return rc;
     const int64_t n = ctx->n, tstride = (int64_t)(num_steps + 1) * n;
     const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;
@@ -162,7 +146,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
         }
         return FEMFCT_OK;
     };
-    auto step = [&](int budget) {
+    auto step = [&](int budget, int) {
         femfct_ctx::GraphKey key{(uint64_t)3, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(uhat), key_bits(p_traj), key_bits(num_steps), key_bits(dt), key_bits(eps),
                                  key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
@@ -180,11 +164,11 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
             int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
                                             dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
-            hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, lv, -1, ctx->d_ctl, ctx->d_log, batch);
+            femfct_enqueue_step_end(ctx, -1, batch, false);
             return FEMFCT_OK;
         });
     };
-    return run_sweep(ctx, num_steps, batch, num_steps - 1, begin, step);
+    return femfct_run_sweep(ctx, num_steps, batch, num_steps - 1, false, begin, step);
 }
 
 // per-step solver diagnostics of the most recent trajectory sweep: info[step*batch + b]

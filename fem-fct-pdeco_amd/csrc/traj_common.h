@@ -1,0 +1,93 @@
+// Shared machinery of the trajectory drivers (traj.hip, traj_systems.hip).
+#pragma once
+
+#include "femfct_internal.h"
+#include "device_utils.h"
+#include "forms.h"
+
+#include <algorithm>
+
+int femfct_ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps);
+int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch);
+int femfct_enqueue_step_end(femfct_ctx* ctx, int delta, int32_t batch, bool with_krylov);
+int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, VecRef rhs,
+                            int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
+                            int64_t out_bstride, int32_t batch, int32_t budget);
+int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
+                         double* out);
+
+static inline int femfct_round_kry_budget(const femfct_ctx* ctx, int b) {
+    b = (b + 3) & ~3;
+    if (b < 4) b = 4;
+    if (b > ctx->kry_max_iters) b = ctx->kry_max_iters;
+    return b;
+}
+
+// Replays `step(jacobi_budget, krylov_budget)` num_steps times, then inspects the per-step solver
+// logs; if a sweep/iteration budget was too small anywhere the whole sweep is repeated with a
+// larger one (the sweep's inputs are never overwritten, so a repeat is exact).
+template <class Begin, class Step>
+int femfct_run_sweep(femfct_ctx* ctx, int32_t num_steps, int32_t batch, int level0, bool krylov, Begin&& begin,
+                     Step&& step) {
+    for (;;) {
+        const int budget = femfct_round_budget(ctx, ctx->sweep_budget);
+        const int kbudget = femfct_round_kry_budget(ctx, ctx->kry_budget);
+        int rc = begin();
+        if (rc != FEMFCT_OK) return rc;
+        int32_t init[2] = {level0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_level, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        for (int32_t k = 0; k < num_steps; ++k) {
+            rc = step(budget, kbudget);
+            if (rc != FEMFCT_OK) return rc;
+        }
+        ctx->h_log.resize((size_t)num_steps * batch);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_log.data(), ctx->d_log, sizeof(StepCtl) * ctx->h_log.size(),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        if (krylov) {
+            ctx->h_klog.resize(sizeof(KrylovCtl) * (size_t)num_steps * batch);
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_klog.data(), ctx->d_klog, ctx->h_klog.size(), hipMemcpyDeviceToHost,
+                                        ctx->stream));
+        } else {
+            ctx->h_klog.clear();
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->log_steps = num_steps;
+        ctx->log_batch = batch;
+        int worst = 0, kworst = 0;
+        bool short_budget = false, kshort = false;
+        double worst_res = 0.0, kworst_res = 0.0;
+        for (const StepCtl& c : ctx->h_log) {
+            worst = std::max(worst, c.iters);
+            if (c.flags & FEMFCT_FLAG_SOLVER_BUDGET) { short_budget = true; worst_res = std::max(worst_res, c.resid); }
+        }
+        if (krylov) {
+            const KrylovCtl* kl = (const KrylovCtl*)ctx->h_klog.data();
+            for (size_t k = 0; k < (size_t)num_steps * batch; ++k) {
+                kworst = std::max(kworst, kl[k].iters);
+                if ((kl[k].flags & FEMFCT_FLAG_SOLVER_BUDGET) || !(kl[k].resid == kl[k].resid)) {
+                    kshort = true;
+                    kworst_res = std::max(kworst_res, kl[k].resid == kl[k].resid ? kl[k].resid : 1.0);
+                }
+            }
+        }
+        if (!short_budget && !kshort) {
+            ctx->sweep_budget = std::min(ctx->max_iters, std::max(8, worst + worst / 8 + 2));
+            if (krylov) ctx->kry_budget = std::min(ctx->kry_max_iters, std::max(8, kworst + kworst / 4 + 2));
+            return FEMFCT_OK;
+        }
+        if (short_budget) {
+            if (budget >= ctx->max_iters)
+                return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
+                                   "low-order solve: residual %.3e after %d Jacobi sweeps (tol %.1e)", worst_res,
+                                   budget, ctx->rel_tol);
+            ctx->sweep_budget = std::min(ctx->max_iters, budget * 2);
+        }
+        if (kshort) {
+            if (kbudget >= ctx->kry_max_iters)
+                return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
+                                   "BiCGStab: residual %.3e after %d iterations (tol %.1e)", kworst_res, kbudget,
+                                   ctx->kry_tol);
+            ctx->kry_budget = std::min(ctx->kry_max_iters, kbudget * 2);
+        }
+    }
+}

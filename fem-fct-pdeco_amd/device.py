@@ -301,3 +301,58 @@ class Context:
     def project_control(self, c, s, d, c_lower, c_upper, out, count):
         check(self.handle, lib.femfct_project_control(self.handle, dptr(c), float(s), dptr(d), float(c_lower),
                                                       float(c_upper), dptr(out), int(count)))
+
+    # -- non-FCT species / PDE systems ---------------------------------------------------
+    def ell_transpose(self, src, out=None) -> DeviceArray:
+        if out is None:
+            out = self.empty(self.W * self.n)
+        check(self.handle, lib.femfct_ell_transpose(self.handle, dptr(src), dptr(out)))
+        return out
+
+    def axpby(self, count, alpha, a, beta, b, out):
+        check(self.handle, lib.femfct_axpby(self.handle, int(count), float(alpha), dptr(a), float(beta), dptr(b), dptr(out)))
+
+    def set_krylov(self, rel_tol=1e-13, max_iters=2000):
+        check(self.handle, lib.femfct_set_krylov(self.handle, float(rel_tol), int(max_iters)))
+
+    def bicgstab(self, mat_ell, b, x0, x, batch=1, mat_shared=False):
+        arr = (StepInfo * batch)()
+        check(self.handle, lib.femfct_bicgstab(self.handle, dptr(mat_ell), int(bool(mat_shared)), dptr(b), dptr(x0),
+                                               dptr(x), int(batch), arr))
+        return [dict(flags=a.flags, solver_iters=a.solver_iters, solver_resid=a.solver_resid) for a in arr]
+
+    def nonlinear_forward(self, Aw, c_level, u, num_steps, dt, eps, batch=1):
+        check(self.handle, lib.femfct_nonlinear_forward(self.handle, dptr(Aw), dptr(c_level), dptr(u), int(num_steps),
+                                                        float(dt), float(eps), int(batch)))
+
+    def nonlinear_adjoint(self, Aw, u, uhat_T, p, num_steps, dt, eps, batch=1):
+        check(self.handle, lib.femfct_nonlinear_adjoint(self.handle, dptr(Aw), dptr(u), dptr(uhat_T), dptr(p),
+                                                        int(num_steps), float(dt), float(eps), int(batch)))
+
+    def schnak_forward(self, Aw, c_level, u, v, num_steps, dt, par, rescaling=1.0, batch=1):
+        par = _as_f64(par)
+        check(self.handle, lib.femfct_schnak_forward(self.handle, dptr(Aw), dptr(c_level), dptr(u), dptr(v),
+                                                     int(num_steps), float(dt), _host_ptr(par), float(rescaling), int(batch)))
+
+    def schnak_adjoint(self, AwT, u, v, uhat_T, vhat_T, p, q, num_steps, dt, par, batch=1):
+        par = _as_f64(par)
+        check(self.handle, lib.femfct_schnak_adjoint(self.handle, dptr(AwT), dptr(u), dptr(v), dptr(uhat_T), dptr(vhat_T),
+                                                     dptr(p), dptr(q), int(num_steps), float(dt), _host_ptr(par), int(batch)))
+
+    def chtxs_forward(self, c_level, u, v, num_steps, dt, par, rescaling=0.1, batch=1):
+        par = _as_f64(par)
+        check(self.handle, lib.femfct_chtxs_forward(self.handle, dptr(c_level), dptr(u), dptr(v), int(num_steps),
+                                                    float(dt), _host_ptr(par), float(rescaling), int(batch)))
+
+    def chtxs_adjoint(self, u, v, uhat, vhat, p, q, c, num_steps, dt, par, rescaling=0.1, alltime=True, batch=1):
+        par = _as_f64(par)
+        check(self.handle, lib.femfct_chtxs_adjoint(self.handle, dptr(u), dptr(v), dptr(uhat), dptr(vhat), dptr(p), dptr(q),
+                                                    dptr(c), int(num_steps), float(dt), _host_ptr(par), float(rescaling),
+                                                    int(bool(alltime)), int(batch)))
+
+    def traj_krylov_info(self, num_steps, batch=1):
+        arr = (StepInfo * (num_steps * batch))()
+        check(self.handle, lib.femfct_traj_krylov_info(self.handle, arr, int(num_steps), int(batch)))
+        return dict(flags=np.array([a.flags for a in arr]).reshape(num_steps, batch),
+                    solver_iters=np.array([a.solver_iters for a in arr]).reshape(num_steps, batch),
+                    solver_resid=np.array([a.solver_resid for a in arr]).reshape(num_steps, batch))

@@ -1,0 +1,289 @@
+"""Drop-in mirrors of the reference's trajectory solvers (same names, argument order and
+in-place mutation behaviour), running as device-resident sweeps through the C ABI:
+
+    solve_nonlinear_equation / solve_adjoint_nonlinear_equation   helpers.py:881-1038
+    solve_schnak_system      / solve_adjoint_schnak_system        helpers.py:511-698
+    solve_chtxs_system       / solve_adjoint_chtxs_system         helpers.py:1250-1581
+    get_*_params / *_IC                                           helpers.py:443-509, 835-879, 1197-1248
+
+``V`` is the ``SquareMeshP1`` descriptor (stand-in for the dolfin FunctionSpace); a ``control_fun``
+is a Python float (the reference passes a constant dolfin Expression for target generation).
+Reference quirks are reproduced: the forward solvers freeze the control at time
+level 1 (helpers.py:577-578, 950-951, 1332-1333) and zero ``var[nodes:]`` in place first.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .device import Context
+from .mesh import SquareMeshP1, reorder_vector_to_dof
+
+
+# ----------------------------------------------------------------------------- parameters
+def schnak_wind(x, y, t=0):
+    """helpers.py:506-508 (stationary: the ``t`` parameter does not enter)."""
+    return 1 * (y - 0.5) * x * (1 - x), -1 * (x - 0.5) * y * (1 - y)
+
+
+def get_schnak_sys_params():
+    """helpers.py:485-509: Du, Dv, c_a, c_b, gamma, omega1, omega2, wind."""
+    return 1 / 100, 8.6676, 0.1, 0.9, 230.82, 100, 0.6, schnak_wind
+
+
+def nonlinear_wind(x, y, speed=1):
+    """helpers.py:876-878."""
+    return speed * 2 * (y - 0.5) * x * (1 - x), -speed * 2 * (x - 0.5) * y * (1 - y)
+
+
+def get_nonlinear_eqns_params():
+    """helpers.py:867-879: eps, speed, wind."""
+    return 1e-4, 1, nonlinear_wind
+
+
+def get_chtxs_sys_params():
+    """helpers.py:1197-1211: delta, Dm, Df, chi, gamma, eta."""
+    return 100, 0.05, 0.05, 0.25, 100, 0.5
+
+
+def _grid(a1, a2, deltax):
+    X = np.arange(a1, a2 + deltax, deltax)
+    return np.meshgrid(X, X)
+
+
+def schnak_sys_IC(a1, a2, deltax, nodes, vertex_to_dof):
+    """helpers.py:443-483."""
+    X, Y = _grid(a1, a2, deltax)
+    _, _, c_a, c_b, _, _, _, _ = get_schnak_sys_params()
+    con = 0.1
+    pert = 0.01 * (sum(np.cos(2 * np.pi * X * i) for i in range(1, 9)))
+    u_init = c_a + c_b + con * np.cos(2 * np.pi * (X + Y)) + pert
+    v_init = c_b / pow(c_a + c_b, 2) + con * np.cos(2 * np.pi * (X + Y)) + pert
+    return (reorder_vector_to_dof(u_init.reshape(nodes), 1, nodes, vertex_to_dof),
+            reorder_vector_to_dof(v_init.reshape(nodes), 1, nodes, vertex_to_dof))
+
+
+def nonlinear_equation_IC(a1, a2, deltax, nodes, vertex_to_dof):
+    """helpers.py:835-865."""
+    X, Y = _grid(a1, a2, deltax)
+    init = 5 * Y * (Y - 1) * X * (X - 1) * np.sin(4 * X * np.pi)
+    return reorder_vector_to_dof(init.reshape(nodes), 1, nodes, vertex_to_dof)
+
+
+def chtxs_sys_IC(a1, a2, deltax, nodes, vertex_to_dof):
+    """helpers.py:1213-1248 (np.random.seed(5); v0 = u0)."""
+    sq = round(np.sqrt(nodes))
+    np.random.seed(5)
+    u_init = 1.5 + 0.1 * (0.5 - np.random.rand(sq, sq))
+    u0 = reorder_vector_to_dof(u_init.reshape(nodes), 1, nodes, vertex_to_dof)
+    return u0, u0
+
+
+# ----------------------------------------------------------------------------- device problem
+class PDESystems:
+    """One GPU context on a structured mesh with the convection matrices of the reference's
+    winds assembled; exposes the device-resident sweeps."""
+
+    def __init__(self, mesh: SquareMeshP1, device_id=0, order=_lib.ORDER_FENICS):
+        self.mesh = mesh
+        self.ctx = Context(device_id)
+        self.ctx.set_mesh_square(mesh.a1, mesh.a2, mesh.n_cells, order)
+        self.n = self.ctx.n
+        self._conv = {}
+
+    def convection(self, wind, name=None):
+        """assemble_sparse(dot(wind, grad(v))*u*dx) on the device (cached per wind)."""
+        key = name or id(wind)
+        if key not in self._conv:
+            xq, yq = self.ctx.quad_points(self.mesh.n_cells)
+            wx, wy = wind(xq, yq)
+            A = self.ctx.assemble_convection(np.stack([wx, wy], axis=1).reshape(-1))
+            self._conv[key] = (A, self.ctx.ell_transpose(A))
+        return self._conv[key]
+
+    def close(self):
+        self.ctx.close()
+
+
+_cache = {}
+
+
+def _system(V: SquareMeshP1) -> PDESystems:
+    if not isinstance(V, SquareMeshP1):
+        raise TypeError("V must be a SquareMeshP1 mesh descriptor (stand-in for the dolfin FunctionSpace)")
+    s = _cache.get(V.key())
+    if s is None:
+        if len(_cache) >= 2:
+            for old in _cache.values():
+                old.close()
+            _cache.clear()
+        s = PDESystems(V)
+        _cache[V.key()] = s
+    return s
+
+
+def _frozen_control(control, control_fun, nodes):
+    if control_fun is not None:
+        return np.full(nodes, float(control_fun))
+    return np.array(control[nodes:2 * nodes], dtype=np.float64)   # level 1 for every step
+
+
+class _Bufs:
+    def __init__(self, ctx):
+        self.ctx, self.items = ctx, []
+
+    def up(self, x):
+        d = self.ctx.array(np.asarray(x, dtype=np.float64).ravel())
+        self.items.append(d)
+        return d
+
+    def zeros(self, count):
+        d = self.ctx.zeros(count)
+        self.items.append(d)
+        return d
+
+    def free(self):
+        for d in self.items:
+            d.free()
+
+
+# ----------------------------------------------------------------------------- nonlinear
+def solve_nonlinear_equation(control, var1, var2, V, nodes, num_steps, dt, dof_neighbors,
+                             control_fun=None, show_plots=False, vertex_to_dof=None):
+    """helpers.py:881-966: mutates ``var1[nodes:]`` in place, returns ``(var1, None)``."""
+    if var2 is not None:
+        warnings.warn("Warning: 'var2' is not None. Ensure this is intentional.")
+    S = _system(V)
+    eps, _, wind = get_nonlinear_eqns_params()
+    Aw, _ = S.convection(wind, "nonlinear")
+    var1[nodes:] = np.zeros(num_steps * nodes)
+    B = _Bufs(S.ctx)
+    try:
+        u = B.up(var1)
+        S.ctx.nonlinear_forward(Aw, B.up(_frozen_control(control, control_fun, nodes)), u, num_steps, dt, eps)
+        u.download(var1)
+    finally:
+        B.free()
+    return var1, None
+
+
+def solve_adjoint_nonlinear_equation(uk, uhat_T, pk, T, V, nodes, num_steps, dt, dof_neighbors):
+    """helpers.py:968-1038: fills ``pk`` (terminal condition included) and returns it."""
+    S = _system(V)
+    eps, _, wind = get_nonlinear_eqns_params()
+    Aw, _ = S.convection(wind, "nonlinear")
+    B = _Bufs(S.ctx)
+    try:
+        p = B.up(pk)
+        S.ctx.nonlinear_adjoint(Aw, B.up(uk), B.up(uhat_T), p, num_steps, dt, eps)
+        p.download(pk)
+    finally:
+        B.free()
+    return pk
+
+
+# ----------------------------------------------------------------------------- Schnakenberg
+def _schnak_par():
+    Du, Dv, _, c_b, gamma, omega1, omega2, wind = get_schnak_sys_params()
+    return [Du, Dv, c_b, gamma, omega1, omega2], wind
+
+
+def solve_schnak_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighbors,
+                        control_fun=None, rescaling=1):
+    """helpers.py:511-597: mutates and returns ``(var1, var2)``."""
+    S = _system(V)
+    par, wind = _schnak_par()
+    Aw, _ = S.convection(wind, "schnak")
+    var1[nodes:] = np.zeros(num_steps * nodes)
+    var2[nodes:] = np.zeros(num_steps * nodes)
+    B = _Bufs(S.ctx)
+    try:
+        u, v = B.up(var1), B.up(var2)
+        S.ctx.schnak_forward(Aw, B.up(_frozen_control(control, control_fun, nodes)), u, v, num_steps, dt, par, rescaling)
+        u.download(var1)
+        v.download(var2)
+    finally:
+        B.free()
+    return var1, var2
+
+
+def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, V, nodes, num_steps, dt, dof_neighbors):
+    """helpers.py:599-698."""
+    S = _system(V)
+    par, wind = _schnak_par()
+    _, AwT = S.convection(wind, "schnak")
+    B = _Bufs(S.ctx)
+    try:
+        p, q = B.up(pk), B.up(qk)
+        S.ctx.schnak_adjoint(AwT, B.up(uk), B.up(vk), B.up(uhat_T), B.up(vhat_T), p, q, num_steps, dt, par)
+        p.download(pk)
+        q.download(qk)
+    finally:
+        B.free()
+    return pk, qk
+
+
+# ----------------------------------------------------------------------------- chemotaxis
+def _chtxs_par():
+    delta, Dm, Df, chi, _, eta = get_chtxs_sys_params()
+    return [delta, Dm, Df, chi, eta]
+
+
+def solve_chtxs_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighbors,
+                       control_fun=None, show_plots=False, vertex_to_dof=None,
+                       generation_mode=False, output_dir=None, rescaling=1 / 10):
+    """helpers.py:1250-1385."""
+    S = _system(V)
+    par = _chtxs_par()
+    B = _Bufs(S.ctx)
+    try:
+        if generation_mode:
+            if len(var1) != nodes or len(var2) != nodes or len(control) != nodes:
+                raise ValueError(f"Generation mode, the input vectors should be of length {nodes}")
+            tl = (num_steps + 1) * nodes
+            u0 = np.zeros(tl)
+            v0 = np.zeros(tl)
+            u0[:nodes], v0[:nodes] = var1, var2
+            c_level = np.full(nodes, float(control_fun)) if control_fun is not None else np.asarray(control, dtype=float)
+            u, v = B.up(u0), B.up(v0)
+            S.ctx.chtxs_forward(B.up(c_level), u, v, num_steps, dt, par, rescaling)
+            if output_dir is not None:
+                uu, vv = u.download(), v.download()
+                t = 0
+                for i in range(1, num_steps + 1):
+                    t += dt
+                    if i % 100 == 0:   # helpers.py:1363-1367
+                        uu[i * nodes:(i + 1) * nodes].tofile(output_dir / f"chtxs_m_t{round(t, 2)}.csv", sep=",")
+                        vv[i * nodes:(i + 1) * nodes].tofile(output_dir / f"chtxs_f_t{round(t, 2)}.csv", sep=",")
+            return var1, var2       # the reference returns its (unchanged) inputs in this mode
+        var1[nodes:] = np.zeros(num_steps * nodes)
+        var2[nodes:] = np.zeros(num_steps * nodes)
+        u, v = B.up(var1), B.up(var2)
+        S.ctx.chtxs_forward(B.up(_frozen_control(control, control_fun, nodes)), u, v, num_steps, dt, par, rescaling)
+        u.download(var1)
+        v.download(var2)
+    finally:
+        B.free()
+    return var1, var2
+
+
+def solve_adjoint_chtxs_system(uk, vk, uhat, vhat, pk, qk, control, T, V, nodes, num_steps, dt,
+                               dof_neighbors, optim, show_plots=None, vertex_to_dof=None, out_folder=None,
+                               mesh=None, deltax=None, rescaling=1 / 10):
+    """helpers.py:1387-1581."""
+    valid_options = ["alltime", "finaltime"]
+    if optim not in valid_options:
+        raise ValueError(f"Invalid value for 'optim': '{optim}'. Must be one of {valid_options}.")
+    S = _system(V)
+    B = _Bufs(S.ctx)
+    try:
+        p, q = B.up(pk), B.up(qk)
+        S.ctx.chtxs_adjoint(B.up(uk), B.up(vk), B.up(uhat), B.up(vhat), p, q, B.up(control), num_steps, dt,
+                            _chtxs_par(), rescaling, optim == "alltime")
+        p.download(pk)
+        q.download(qk)
+    finally:
+        B.free()
+    return pk, qk

@@ -207,6 +207,51 @@ int femfct_cost_functional(femfct_ctx* ctx, const double* var1, const double* va
 int femfct_project_control(femfct_ctx* ctx, const double* c_dev, double s, const double* d_dev,
                            double c_lower, double c_upper, double* out_dev, int64_t count);
 
+/* ------------------------------------------------ non-FCT species and the three PDE systems */
+
+/* out = in^T on the registered pattern: assemble_sparse(dot(wind,grad(u))*w*dx) (helpers.py:681) is the
+ * transpose of assemble_sparse(dot(wind,grad(w))*u*dx) (helpers.py:581) */
+int femfct_ell_transpose(femfct_ctx* ctx, const double* in_ell, double* out_ell);
+/* out = alpha*a + beta*b over count doubles (b may be NULL): Du*Ad - omega1*A etc. (helpers.py:583) */
+int femfct_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a_dev, double beta,
+                 const double* b_dev, double* out_dev);
+/* tolerance / iteration cap of the BiCGStab used for the non-FCT implicit solves */
+int femfct_set_krylov(femfct_ctx* ctx, double rel_tol, int32_t max_iters);
+/* spsolve(Mat, b) (helpers.py:596,686,1342,1538): Jacobi-preconditioned BiCGStab from the initial guess
+ * x0; mat_shared != 0: one matrix for the whole batch.  Synchronises. */
+int femfct_bicgstab(femfct_ctx* ctx, const double* mat_ell, int32_t mat_shared, const double* b_dev,
+                    const double* x0_dev, double* x_dev, int32_t batch, femfct_step_info* info_host);
+
+/* solve_nonlinear_equation (helpers.py:881-966).  Aw_ell = assemble_sparse(dot(wind,grad(v))*u*dx);
+ * c_level = the control level the reference uses for the whole sweep (level 1, helpers.py:950-951; or
+ * the constant control_fun), n doubles per batch member; u_traj level 0 = initial condition. */
+int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c_level, double* u_traj,
+                             int32_t num_steps, double dt, double eps, int32_t batch);
+/* solve_adjoint_nonlinear_equation (helpers.py:968-1038); uhat_T: n doubles per batch member */
+int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double* u_traj,
+                             const double* uhat_T, double* p_traj, int32_t num_steps, double dt, double eps,
+                             int32_t batch);
+/* solve_schnak_system (helpers.py:511-597); par = {Du, Dv, c_b, gamma, omega1, omega2} */
+int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c_level, double* u_traj,
+                          double* v_traj, int32_t num_steps, double dt, const double* par, double rescaling,
+                          int32_t batch);
+/* solve_adjoint_schnak_system (helpers.py:599-698); AwT_ell = femfct_ell_transpose(Aw_ell) */
+int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* u_traj, const double* v_traj,
+                          const double* uhat_T, const double* vhat_T, double* p_traj, double* q_traj,
+                          int32_t num_steps, double dt, const double* par, int32_t batch);
+/* solve_chtxs_system (helpers.py:1250-1385, non-generation mode); par = {delta, Dm, Df, chi, eta} */
+int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj, double* v_traj,
+                         int32_t num_steps, double dt, const double* par, double rescaling, int32_t batch);
+/* solve_adjoint_chtxs_system (helpers.py:1387-1581); alltime = 0: optim "finaltime" (uhat/vhat n doubles
+ * per member), 1: optim "alltime" (uhat/vhat trajectories; raw nodal misfits as in helpers.py:1506-1507,
+ * 1533-1534; level num_steps of p/q is taken as passed) */
+int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_traj, const double* uhat,
+                         const double* vhat, double* p_traj, double* q_traj, const double* c_traj,
+                         int32_t num_steps, double dt, const double* par, double rescaling, int32_t alltime,
+                         int32_t batch);
+/* BiCGStab diagnostics of the most recent sweep that used it: info_host[step*batch + b] */
+int femfct_traj_krylov_info(femfct_ctx* ctx, femfct_step_info* info_host, int32_t num_steps, int32_t batch);
+
 #ifdef __cplusplus
 }
 #endif
