@@ -119,3 +119,78 @@ class SolidBodyDrift:
 
     def close(self):
         self.ctx.close()
+
+
+def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower, c_upper, iters,
+                            gam=1e-4, s0=1.0, max_armijo=10, speculative=True, tol=None):
+    """Projected gradient descent for the final-time drift-control problem, following the loop of
+    advection_solidbody_FCT_PDECO_finaltime_Garvie.py:164-330 step for step:
+
+        adjoint(c_prev, u) -> d = ChebSI(-(beta M c_prev + int p (b.grad u) v)) -> c = clip(c_prev + s0 d)
+        -> state(c) -> J_k -> Armijo: trials c_inc = clip(c + s d), s = s0/2^k, accept the first with
+        J(c_inc) - J_k <= -gam/s ||c_inc - c||^2_Q  (else the last) -> c_prev = c_inc
+
+    Everything stays in HBM; the host sees scalars only.  ``speculative=True`` evaluates all
+    ``max_armijo`` trial steps as one batch of independent trajectories (same launches, B = max_armijo)
+    and picks the first accepted one -- the same iterate as the sequential search, bit for bit.
+    Returns ``(u, p, c, history)`` as NumPy arrays + a dict of per-iteration scalars."""
+    ctx, n, Nt, dt, tl = prob.ctx, prob.n, prob.num_steps, prob.dt, prob.tlen
+    B = int(max_armijo) if speculative else 1
+    u = ctx.zeros(tl)
+    u.upload(np.concatenate([np.asarray(u0, dtype=np.float64), np.zeros(tl - n)]))
+    # the reference seeds u(T) with the target before the first adjoint solve (finaltime.py:146)
+    p, d, c, rhs = ctx.zeros(tl), ctx.zeros(tl), ctx.zeros(tl), ctx.empty(tl)
+    c_prev = ctx.array(np.asarray(c0, dtype=np.float64))
+    uh = ctx.array(uhat_T)
+    uhB = ctx.array(np.tile(np.asarray(uhat_T, dtype=np.float64), B))
+    cB, uB, ckB = ctx.zeros(B * tl), ctx.zeros(B * tl), ctx.zeros(B * tl)
+    init = np.zeros((B, tl))
+    init[:, :n] = u0
+    uB.upload(init.reshape(-1))
+    hist = dict(cost=[], armijo_k=[], step=[], rel_change=[])
+    # uk(T) = uhat_T initially (finaltime_Garvie.py: uk[num_steps*nodes:] = uhat_T)
+    u.copy_from(uh, n, dst_off=Nt * n)
+    try:
+        for it in range(iters):
+            prob.adjoint(c_prev, u, uh, p, "finaltime", batch=1)
+            prob.descent_direction(c_prev, u, p, beta, d, scratch=rhs)
+            ctx.project_control(c_prev, s0, d, c_lower, c_upper, c, tl)
+            prob.forward(c, u, batch=1)
+            J_k = float(prob.cost(u, uh, c, beta, "finaltime", batch=1)[0])
+            svals = [s0 * (1 / 2 ** k) for k in range(max_armijo)]
+            accepted = None
+            if speculative:
+                for k, s in enumerate(svals):
+                    ctx.project_control(c, s, d, c_lower, c_upper, cB.ptr + 8 * k * tl, tl)
+                    ckB.copy_from(c, tl, dst_off=k * tl)
+                prob.forward(cB, uB, batch=B)
+                J = prob.cost(uB, uhB, cB, beta, "finaltime", batch=B)
+                stat = ctx.l2_norm_sq_Q(cB, ckB, Nt, dt, batch=B)
+                for k, s in enumerate(svals):
+                    accepted = k
+                    if not (J[k] - J_k > -gam / s * stat[k]):
+                        break
+                J_acc = float(J[accepted])
+                c_prev.copy_from(cB, tl, src_off=accepted * tl)
+                u.copy_from(uB, tl, src_off=accepted * tl)
+            else:
+                for k, s in enumerate(svals):
+                    accepted = k
+                    ctx.project_control(c, s, d, c_lower, c_upper, cB, tl)
+                    prob.forward(cB, uB, batch=1)
+                    J_acc = float(prob.cost(uB, uh, cB, beta, "finaltime", batch=1)[0])
+                    stat = float(ctx.l2_norm_sq_Q(cB, c, Nt, dt)[0])
+                    if not (J_acc - J_k > -gam / s * stat):
+                        break
+                c_prev.copy_from(cB, tl)
+                u.copy_from(uB, tl)
+            hist["cost"].append(J_acc)
+            hist["armijo_k"].append(accepted + 1)
+            hist["step"].append(svals[accepted])
+            hist["rel_change"].append(abs(J_k - J_acc) / abs(J_k))
+            if tol is not None and hist["rel_change"][-1] < tol:
+                break
+        return u.download(), p.download(), c_prev.download(), hist
+    finally:
+        for a in (u, p, d, c, rhs, c_prev, uh, uhB, cB, uB, ckB):
+            a.free()

@@ -287,3 +287,57 @@ def solve_adjoint_chtxs_system(uk, vk, uhat, vhat, pk, qk, control, T, V, nodes,
     finally:
         B.free()
     return pk, qk
+
+
+# ----------------------------------------------------------------------------- assembly bridge
+def assemble_mass(V: SquareMeshP1):
+    """``assemble_sparse(u*v*dx)`` (helpers.py:87-104, 553): the device-assembled mass matrix as a
+    scipy CSR matrix in FEniCS DoF order."""
+    from scipy.sparse import csr_matrix
+    S = _system(V)
+    ctx = S.ctx
+    cols = ctx.ell_cols()
+    n, W = ctx.n, ctx.W
+    rows = np.tile(np.arange(n), W)
+    flat = cols.reshape(-1)
+    mask = (flat != rows) | (np.arange(W * n) < n)
+    r, c = rows[mask], flat[mask]
+    order = np.lexsort((c, r))
+    vals = ctx.ell_to_csr(ctx.mass_ell, int(mask.sum()))
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))])
+    return csr_matrix((vals, c[order], indptr), shape=(n, n))
+
+
+# ----------------------------------------------------------------------------- line search
+def armijo_line_search_ref(var1, c, d, var1_target, num_steps, dt, c_lower, c_upper, beta, costfun_init,
+                           nodes, optim, V, gam=1e-4, max_iter=10, s0=1, nonlinear_solver=None,
+                           dof_neighbors=None, var2=None, var2_target=None, w1=None, w2=None):
+    """Projected Armijo line search, helpers.py:1583-1713 (live branch: ``w1 is None``; with ``w1``
+    given the reference leaves ``M = None`` and fails inside cost_functional, :1654-1663).
+    The host loop stays in Python as in the reference; every trial's state solve and both
+    norm evaluations run on the GPU.  Returns ``(var1[, var2], c_inc, k+1)``; the caller detects
+    failure by ``k+1 == max_iter`` (nonlinear_FCT_PDECO_refactored.py:161)."""
+    from .fct_helpers import cost_functional, L2_norm_sq_Q
+    valid_options = ["alltime", "finaltime"]
+    if optim not in valid_options:
+        raise ValueError(f"Invalid value for 'optim': '{optim}'. Must be one of {valid_options}.")
+    if w1 is not None or w2 is not None:
+        raise ValueError("armijo_line_search_ref: the linear-increment branch (w1/w2) is dead in the "
+                         "reference (M is None there); pass nonlinear_solver instead")
+    M = assemble_mass(V)
+    s = s0
+    armijo = float("inf")
+    control_dif_L2 = 1
+    k = 0
+    c_inc = c
+    for k in range(max_iter):
+        c_inc = np.clip(c + s * d, c_lower, c_upper)
+        var1, var2 = nonlinear_solver(c_inc, var1, var2, V, nodes, num_steps, dt, dof_neighbors)
+        cost2 = cost_functional(var1, var1_target, c_inc, num_steps, dt, M, beta, optim=optim,
+                                var2=var2, var2_target=var2_target)
+        armijo = cost2 - costfun_init
+        control_dif_L2 = L2_norm_sq_Q(c_inc - c, num_steps, dt, M)
+        if armijo <= -gam / s * control_dif_L2:
+            break
+        s /= 2
+    return (var1, var2, c_inc, k + 1) if var2 is not None else (var1, c_inc, k + 1)
