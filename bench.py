@@ -111,20 +111,25 @@ def main():
     tl = (Nt + 1) * n
     betas = [10.0 ** (-k / 2) for k in range(8)]          # C5 sweep values
     beta = betas[rank % len(betas)] if world > 1 else 1.0  # C2: beta = 1
-    prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=local_rank)
+    # device arrays live in dolfin vertex order (the library's fast layout: index-free stencil
+    # addressing + 2-D tile kernels); the DoF-ordered arrays below feed the CPU oracle
+    prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=local_rank,
+                                  order=hp.ORDER_VERTEX)
     ctx = prob.ctx
+    to_dev = lambda x: hp.reorder_vector_from_dof(x, x.size // n, n, mesh.vertex_to_dof)
     u0 = hp.reorder_vector_to_dof(slotted_disc_ic(a1, a2, deltax), 1, n, mesh.vertex_to_dof)
     ck = synthetic_control(mesh, Nt, seed=rank)
     gpath = os.path.join(ROOT, "tests", "golden", "solidbody_t0.25_u.npz")
     uhat = np.load(gpath)["u"] if os.path.exists(gpath) else np.roll(u0, 7)
     init = np.zeros((B, tl))
     init[:, :n] = u0
-    d_c = ctx.array(np.tile(ck, B))
+    init[:, :n] = to_dev(u0)
+    d_c = ctx.array(np.tile(to_dev(ck), B))
     d_u = ctx.array(init.reshape(-1))
     d_p = ctx.zeros(B * tl)
     d_d = ctx.zeros(tl)
     d_rhs = ctx.empty(tl)
-    d_uhat = ctx.array(np.tile(uhat, B))
+    d_uhat = ctx.array(np.tile(to_dev(uhat), B))
 
     def one_step():
         prob.forward(d_c, d_u, batch=B)

@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <tuple>
@@ -81,6 +82,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     if (ctx->d_klog) { hipFree(ctx->d_klog); ctx->d_klog = nullptr; }
     ctx->kry_batch = 0;
     dev_free(&ctx->d_trMat); dev_free(&ctx->d_trBase); dev_free(&ctx->d_trBase2); dev_free(&ctx->d_trRhs2); dev_free(&ctx->d_trTmp);
+    ctx->implicit_cols = false;
     ctx->n = 0; ctx->W = 0; ctx->nnz_csr = 0; ctx->ws_batch = 0; ctx->have_mass = false; ctx->structured = false;
 }
 
@@ -121,6 +123,28 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     return FEMFCT_OK;
 }
 
+int femfct_fused_k(const femfct_ctx* ctx) {
+    TilePlan tp;
+    if (femfct_tile_plan(ctx, &tp)) return tp.K;
+    StripPlan pl;
+    if (femfct_strip_plan(ctx, &pl)) return pl.K;
+    return 1;
+}
+
+int femfct_next_budget(const femfct_ctx* ctx, int worst) {
+    const int K = femfct_fused_k(ctx);
+    int b;
+    if (K > 1) b = ((std::max(worst, 1) + K - 1) / K) * K;   // whole launches, no margin
+    else b = std::max(8, worst + worst / 8 + 2);
+    return std::min(ctx->max_iters, b);
+}
+
+int femfct_grow_budget(const femfct_ctx* ctx, int budget) {
+    const int K = femfct_fused_k(ctx);
+    if (K > 1) return std::min(ctx->max_iters, budget + K);
+    return std::min(ctx->max_iters, budget * 2);
+}
+
 int femfct_round_budget(const femfct_ctx* ctx, int b) {
     b = (b + 3) & ~3;
     if (b < 4) b = 4;
@@ -141,7 +165,18 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if ((rc = dev_alloc(ctx, &ctx->d_M, (size_t)W * n)) != FEMFCT_OK) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_ml, (size_t)n)) != FEMFCT_OK) return rc;
     ctx->h_cols = cols;
-    return FEMFCT_OK;
+    int32_t bwmax = 0;
+    for (int32_t s = 1; s < W; ++s)
+        for (int32_t i = 0; i < n; ++i) {
+            int32_t d = cols[(size_t)s * n + i] - i;
+            if (d < 0) d = -d;
+            if (d > bwmax) bwmax = d;
+        }
+    ctx->bandwidth = bwmax;
+    if (const char* e = getenv("FEMFCT_STRIPS")) ctx->use_strips = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_STRIP_K")) ctx->strip_k = atoi(e);
+    if (const char* e = getenv("FEMFCT_TILES")) ctx->use_tiles = atoi(e) != 0;
+    return femfct_strip_init(ctx);
 }
 
 // host CSR <-> ELL map for a pattern whose ELL cols are known (h_cols) and CSR given
@@ -446,8 +481,8 @@ int femfct_last_step_info(femfct_ctx* ctx, femfct_step_info* info, int32_t batch
         info[b].min_rowsum = h[b].min_rowsum;
         worst = std::max(worst, h[b].iters);
     }
-    // adapt the number of sweeps enqueued per step to what the operator needs (+ margin)
-    ctx->sweep_budget = std::min(ctx->max_iters, std::max(8, worst + 4));
+    // adapt the number of sweeps enqueued per step to what the operator needs
+    if (!(h[0].flags & FEMFCT_FLAG_SOLVER_BUDGET)) ctx->sweep_budget = femfct_next_budget(ctx, worst);
     return FEMFCT_OK;
 }
 
@@ -480,7 +515,7 @@ int femfct_fct_step_host(femfct_ctx* ctx, const double* A_csr, const double* N_c
             return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
                                "low-order solve: residual %.3e after %d sweeps (tol %.1e)", local.solver_resid,
                                local.solver_iters, ctx->rel_tol);
-        ctx->sweep_budget = std::min(ctx->max_iters, used_budget * 2);
+        ctx->sweep_budget = femfct_grow_budget(ctx, used_budget);
     }
     if (info) *info = local;
     HIP_TRY(ctx, hipMemcpyAsync(u_out, ctx->d_hout, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));

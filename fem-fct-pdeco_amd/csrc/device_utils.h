@@ -29,11 +29,9 @@ static inline VecRef make_ref(const double* p, const int32_t* level, int64_t str
 }
 
 // ---------------------------------------------------------------------------
-// Row partitioning.  gridDim.x blocks each own one contiguous chunk of rows;
-// consecutive chunks go to the same XCD (blocks are dealt round-robin over the 8
-// XCDs, each with a private L2), so neighbouring rows -- which share x-vector
-// halo lines -- hit the same L2.  The remap is bijective for any grid size and
-// only affects speed.
+// Row partitioning.  gridDim.x blocks each own one contiguous chunk of rows.  xcd_remap makes
+// consecutive chunks land on the same XCD (blocks are dealt round-robin over the 8 XCDs, each with
+// a private L2); it is bijective for any grid size and only affects speed.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int xcd_remap(int b, int G) {
     int q = G >> 3, r = G & 7;
@@ -43,9 +41,16 @@ __device__ __forceinline__ int xcd_remap(int b, int G) {
 
 struct RowRange { int begin, end; };
 
+// Measured on MI355X (tools/bw_probe.hip, 7 value streams + 6 gathers, n = 2049^2): the plain
+// block -> chunk map streams 4-15 % faster than the XCD-contiguous remap (8 XCDs x 11 streams far
+// apart cost more DRAM locality than the shared x-halo lines save in L2), so the remap is off.
+#ifndef FEMFCT_XCD_REMAP
+#define FEMFCT_XCD_REMAP 0
+#endif
+
 __device__ __forceinline__ RowRange block_rows(int n) {
     int G = gridDim.x;
-    int lb = xcd_remap(blockIdx.x, G);
+    int lb = FEMFCT_XCD_REMAP ? xcd_remap(blockIdx.x, G) : (int)blockIdx.x;
     int chunk = (n + G - 1) / G;
     // keep chunks a multiple of the wave size so that wave loads stay aligned
     chunk = (chunk + WAVE - 1) & ~(WAVE - 1);

@@ -12,7 +12,9 @@
 #include "../../include/femfct.h"
 
 #define FEMFCT_MAX_W 16          // widest ELL row supported (P1 structured mesh: 7)
-#define FEMFCT_MAX_PARTIALS 2048 // cap on per-kernel block partials (grid-stride beyond)
+#ifndef FEMFCT_MAX_PARTIALS
+#define FEMFCT_MAX_PARTIALS 2048 // cap on per-kernel block partials (row chunks beyond)
+#endif
 
 // ---------------------------------------------------------------------------
 // device-side control block of one low-order solve / step (one per batch member)
@@ -56,8 +58,14 @@ struct femfct_ctx {
     int solver = FEMFCT_SOLVER_JACOBI;
     double rel_tol = 1e-13;
     int max_iters = 400;
-    int sweep_budget = 48;      // adaptive: sweeps enqueued per step
+    int sweep_budget = 48;      // adaptive: sweeps enqueued per step (stand-alone femfct_fct_step)
+    std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
+    bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
+    bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    int32_t bandwidth = 0;      // max |col - row| of the pattern
+    int32_t strip_k = 0;        // 0: automatic
+    bool implicit_cols = false; // structured mesh in vertex order: neighbour index = row + const offset
 
     // workspace (sized for ws_batch systems)
     int32_t ws_batch = 0;
@@ -135,6 +143,29 @@ static inline uint64_t key_bits(int32_t v) { return (uint64_t)(int64_t)v; }
 // Run `enqueue` (a callable that launches kernels on ctx->stream) through a cached hipGraph.
 template <class F>
 int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue);
+
+// strip-fused kernels (kernels_strip.hip)
+struct StripPlan { int K, R, bw, rpt, S; };
+bool femfct_strip_plan(const femfct_ctx* ctx, StripPlan* pl);
+int femfct_strip_init(femfct_ctx* ctx);
+int femfct_enqueue_strip_jacobi(femfct_ctx* ctx, const StripPlan& pl, const double* L, const double* b, double* xa,
+                                double* xb, int launch, int g_build, int32_t batch);
+int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double* b, const double* in_mid,
+                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
+                              double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1,
+                              int32_t batch);
+struct TilePlan { int tiles, K; };
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl);
+int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
+                               double* xb, int launch, int g_build, int32_t batch);
+int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
+                             const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
+                             double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch);
+// number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
+int femfct_fused_k(const femfct_ctx* ctx);
+// sweep-budget policy (sweeps to enqueue for the next step sequence)
+int femfct_next_budget(const femfct_ctx* ctx, int worst_iters);
+int femfct_grow_budget(const femfct_ctx* ctx, int budget);
 
 // kernel classes for profiling
 enum { KC_BUILD_LOW = 0, KC_JACOBI, KC_DUDT_RHS, KC_CHEB, KC_FLUX, KC_LIMIT, KC_ASSEMBLE, KC_OTHER, KC_COUNT };

@@ -30,11 +30,42 @@ __device__ __forceinline__ const double* sel(const StepCtl* ctl, const double* x
     return ctl->parity ? xb : xa;
 }
 
+
+// Column index of slot s in row i.  IMP = 0: explicit ELL column table (any pattern / ordering).
+// IMP = 1: structured mesh in vertex order -- the neighbour is i + const offset, so no index bytes are
+// read and the x-gather does not wait for an index load; slots that fall outside the grid resolve
+// to the row itself, exactly like the padded entries of the explicit table.
+template <int IMP>
+__device__ __forceinline__ unsigned nb_mask(int i, int Nw) {
+    if (!IMP) return 0u;
+    const int iy = i / Nw, ix = i - iy * Nw;
+    const unsigned e = ix < Nw - 1, w = ix > 0, nn = iy < Nw - 1, ss = iy > 0;
+    return (e << 1) | ((e & nn) << 2) | (nn << 3) | (w << 4) | ((w & ss) << 5) | (ss << 6);
+}
+
+template <int IMP>
+__device__ __forceinline__ int col_of(const int32_t* __restrict__ cols, int n, int Nw, unsigned mask, int s, int i) {
+    if (IMP) {
+        const int off = (s == 1) ? 1 : (s == 2) ? Nw + 1 : (s == 3) ? Nw : (s == 4) ? -1 : (s == 5) ? -Nw - 1 : -Nw;
+        return ((mask >> s) & 1u) ? i + off : i;
+    }
+    return cols[(int64_t)s * n + i];
+}
+
+template <int IMP>
+__device__ __forceinline__ int tslot_of(const uint8_t* __restrict__ tslot, int n, unsigned mask, int s, int i) {
+    if (IMP) {
+        const int opp = (s < 4) ? s + 3 : s - 3;
+        return ((mask >> s) & 1u) ? opp : s;
+    }
+    return tslot[(int64_t)s * n + i];
+}
+
 // ---------------------------------------------------------------------------
 // k_build_low: artificial diffusion + low-order operator + rhs (helpers.py:1769-1780)
 // ---------------------------------------------------------------------------
-template <int WT, int BS>
-__global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, const int32_t* __restrict__ cols,
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const int32_t* __restrict__ cols,
                             const uint8_t* __restrict__ tslot, const double* __restrict__ A_,
                             const double* __restrict__ N_, int nshared, VecRef rhs_ref, VecRef u_ref,
                             int64_t rhs_bstride, int64_t u_bstride,
@@ -64,12 +95,13 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, const int32_t*
     RowRange rr = block_rows(n);
     double bmax = 0.0, rsmin = INFINITY;
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        const unsigned mask = nb_mask<IMP>(i, Nw);
         double dsum = 0.0, rs = 0.0;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            int j = cols[idx];
-            int ts = tslot[idx];
+            int j = col_of<IMP>(cols, n, Nw, mask, s, i);
+            int ts = tslot_of<IMP>(tslot, n, mask, s, i);
             double a = A[idx];
             double at = A[(int64_t)ts * n + j];
             double d = (j != i) ? fmax(0.0, fmax(a, at)) : 0.0;   // d_ij = max(0, a_ij, a_ji)
@@ -108,8 +140,8 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, const int32_t*
 // Since x_new - x_old = Dg^-1 r(x_old), every sweep also yields the true residual
 // of its input iterate; convergence is decided on the device from those.
 // ---------------------------------------------------------------------------
-template <int WT, int BS>
-__global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ L_,
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ L_,
                          const double* __restrict__ b_, double* __restrict__ xa_, double* __restrict__ xb_,
                          double* __restrict__ part, StepCtl* __restrict__ ctl_, int sweep, double rel_tol) {
     __shared__ double smem[32];
@@ -148,11 +180,12 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, const int32_t* __
     RowRange rr = block_rows(n);
     double rmax = 0.0;
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        const unsigned mask = nb_mask<IMP>(i, Nw);
         double acc = b[i];
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            acc -= L[idx] * xin[cols[idx]];
+            acc -= L[idx] * xin[col_of<IMP>(cols, n, Nw, mask, s, i)];
         }
         double ld = L[i];
         double xi = xin[i];
@@ -165,8 +198,8 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, const int32_t* __
 }
 
 // Finalise the solve bookkeeping when the sweep budget ran out before `done`.
-__device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, int budget, double rel_tol,
-                                               double* smem) {
+__device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, int budget, int iters_per_unit,
+                                               double rel_tol, double* smem) {
     if (ctl->done) return;
     double rmax = reduce_partials(p + ((budget - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
     // every block computes the same values; block 0 publishes them for later kernels' diagnostics.
@@ -174,7 +207,7 @@ __device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, i
     // later kernels, never by other blocks of this kernel).
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double bn = ctl->bnorm;
-        ctl->iters = budget;
+        ctl->iters = budget * iters_per_unit;
         ctl->resid = bn > 0.0 ? rmax / bn : 0.0;
         if (!(rmax <= rel_tol * bn)) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
     }
@@ -184,13 +217,13 @@ __device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, i
 // k_dudt_rhs: r = rhs - A u_L (helpers.py:1814) fused with Chebyshev iterate 1
 // (y_1 = omega_1 * r / (1.25 diag M), helpers.py:175-182 with y_0 = y_-1 = 0).
 // ---------------------------------------------------------------------------
-template <int WT, int BS>
-__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ A_,
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ A_,
                            VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
                            const double* __restrict__ xa_, const double* __restrict__ xb_,
                            double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
-                           double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, double rel_tol,
-                           double md_scale, double omega1) {
+                           double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, int part_count,
+                           int iters_per_unit, double rel_tol, double md_scale, double omega1) {
     __shared__ double smem[32];
     const int W = WT ? WT : Wrt;
     const int bz = blockIdx.y;
@@ -198,7 +231,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, const int32_t* 
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     // solution buffer: decided by the sweep that detected convergence, else by the budget parity
     const int parity = ctl->done ? ctl->parity : (budget & 1);
-    finalize_solve(ctl, p, gridDim.x, budget, rel_tol, smem);
+    finalize_solve(ctl, p, part_count ? part_count : gridDim.x, budget, iters_per_unit, rel_tol, smem);
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const double* A = A_ + moff;
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -209,12 +242,13 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, const int32_t* 
     double* y1 = y1_ + voff;
     RowRange rr = block_rows(n);
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        const unsigned mask = nb_mask<IMP>(i, Nw);
         double xi = x[i];
         double acc = A[i] * xi;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            acc += A[idx] * x[cols[idx]];
+            acc += A[idx] * x[col_of<IMP>(cols, n, Nw, mask, s, i)];
         }
         double r = -acc + (rhs ? rhs[i] : 0.0);
         rdu[i] = r;
@@ -227,8 +261,8 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, const int32_t* 
 // k_cheb: one Chebyshev semi-iteration step (helpers.py:175-184)
 //   r = b - M y_mid ; z = r / Md ; y_new = omega (z + y_mid - y_old) + y_old
 // ---------------------------------------------------------------------------
-template <int WT, int BS>
-__global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ M,
                        const double* __restrict__ b_, const double* __restrict__ ymid_,
                        const double* __restrict__ yold_, double* __restrict__ ynew_, double omega,
                        double md_scale) {
@@ -240,6 +274,7 @@ __global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, const int32_t* __re
     double* ynew = ynew_ + voff;
     RowRange rr = block_rows(n);
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        const unsigned mask = nb_mask<IMP>(i, Nw);
         double md = M[i];
         double ym = ymid ? ymid[i] : 0.0;
         double acc = md * ym;
@@ -247,7 +282,7 @@ __global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, const int32_t* __re
 #pragma unroll
             for (int s = 1; s < W; ++s) {
                 int64_t idx = (int64_t)s * n + i;
-                acc += M[idx] * ymid[cols[idx]];
+                acc += M[idx] * ymid[col_of<IMP>(cols, n, Nw, mask, s, i)];
             }
         }
         double r = b[i] - acc;
@@ -260,8 +295,8 @@ __global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, const int32_t* __re
 // ---------------------------------------------------------------------------
 // k_flux: raw antidiffusive fluxes + Zalesak P/Q/R (helpers.py:1818-1851)
 // ---------------------------------------------------------------------------
-template <int WT, int BS>
-__global__ void __launch_bounds__(BS) k_flux(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ M,
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_flux(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ M,
                        const double* __restrict__ D_, const double* __restrict__ ulow_,
                        const double* __restrict__ du_, const double* __restrict__ ml, double dt,
                        double* __restrict__ F_, double* __restrict__ rp_, double* __restrict__ rm_) {
@@ -276,12 +311,13 @@ __global__ void __launch_bounds__(BS) k_flux(int n, int Wrt, const int32_t* __re
     double* rm = rm_ + voff;
     RowRange rr = block_rows(n);
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        const unsigned mask = nb_mask<IMP>(i, Nw);
         double ui = ulow[i], dui = du[i];
         double pp = 0.0, pm = 0.0, umax = ui, umin = ui;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            int j = cols[idx];
+            int j = col_of<IMP>(cols, n, Nw, mask, s, i);
             double uj = ulow[j];
             double f = M[idx] * (dui - du[j]) + D[idx] * (ui - uj);
             F[idx] = f;
@@ -300,8 +336,8 @@ __global__ void __launch_bounds__(BS) k_flux(int n, int Wrt, const int32_t* __re
 // ---------------------------------------------------------------------------
 // k_limit: alpha_ij, limited flux sum and explicit correction (helpers.py:1860-1870)
 // ---------------------------------------------------------------------------
-template <int WT, int BS>
-__global__ void __launch_bounds__(BS) k_limit(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ F_,
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_limit(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ F_,
                         const double* __restrict__ rp_, const double* __restrict__ rm_,
                         const double* __restrict__ ulow_, const double* __restrict__ ml, double dt,
                         VecRef out_ref, int64_t out_bstride) {
@@ -315,12 +351,13 @@ __global__ void __launch_bounds__(BS) k_limit(int n, int Wrt, const int32_t* __r
     double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
     RowRange rr = block_rows(n);
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        const unsigned mask = nb_mask<IMP>(i, Nw);
         double rpi = rp[i], rmi = rm[i];
         double fbar = 0.0;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            int j = cols[idx];
+            int j = col_of<IMP>(cols, n, Nw, mask, s, i);
             double f = F[idx];
             double a = (f > 0.0) ? fmin(rpi, rm[j]) : fmin(rmi, rp[j]);
             fbar += a * f;
@@ -400,12 +437,15 @@ static void cheb_omegas(int iters, double lmin, double lmax, std::vector<double>
 #define LAUNCH_W(cls, kern, geom, stream, ...)                                                          \
     do {                                                                                                \
         femfct_prof_begin(ctx, cls);                                                                    \
-        if (ctx->W == 7) {                                                                              \
-            if (geom.block.x == 64) hipLaunchKernelGGL((kern<7, 64>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
-            else hipLaunchKernelGGL((kern<7, 256>), geom.grid, geom.block, 0, stream, __VA_ARGS__);      \
+        if (ctx->W == 7 && ctx->implicit_cols) {                                                        \
+            if (geom.block.x == 64) hipLaunchKernelGGL((kern<7, 64, 1>), geom.grid, geom.block, 0, stream, __VA_ARGS__);  \
+            else hipLaunchKernelGGL((kern<7, 256, 1>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
+        } else if (ctx->W == 7) {                                                                       \
+            if (geom.block.x == 64) hipLaunchKernelGGL((kern<7, 64, 0>), geom.grid, geom.block, 0, stream, __VA_ARGS__);  \
+            else hipLaunchKernelGGL((kern<7, 256, 0>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
         } else {                                                                                        \
-            if (geom.block.x == 64) hipLaunchKernelGGL((kern<0, 64>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
-            else hipLaunchKernelGGL((kern<0, 256>), geom.grid, geom.block, 0, stream, __VA_ARGS__);      \
+            if (geom.block.x == 64) hipLaunchKernelGGL((kern<0, 64, 0>), geom.grid, geom.block, 0, stream, __VA_ARGS__);  \
+            else hipLaunchKernelGGL((kern<0, 256, 0>), geom.grid, geom.block, 0, stream, __VA_ARGS__);   \
         }                                                                                               \
         femfct_prof_end(ctx);                                                                           \
     } while (0)
@@ -417,6 +457,23 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
     std::vector<double> om;
     cheb_omegas(iters, lmin, lmax, om);
     const double md_scale = (lmin + lmax) / 2.0;
+    TilePlan tp;
+    if (femfct_tile_plan(ctx, &tp)) {
+        if (first_done_in_y1)
+            return femfct_enqueue_tile_cheb(ctx, tp, b, ctx->d_y1, nullptr, y_out, 2, iters, om.data(), md_scale,
+                                            ctx->d_y0, ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
+        return femfct_enqueue_tile_cheb(ctx, tp, b, nullptr, nullptr, y_out, 1, iters, om.data(), md_scale, ctx->d_y0,
+                                        ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
+    }
+    StripPlan pl;
+    if (femfct_strip_plan(ctx, &pl)) {
+        // y_1 (if already produced by k_dudt_rhs) lives in d_y1; pairs (y0,y2) / (y1,rp) alternate as scratch
+        if (first_done_in_y1)
+            return femfct_enqueue_strip_cheb(ctx, pl, b, ctx->d_y1, nullptr, y_out, 2, iters, om.data(), md_scale,
+                                             ctx->d_y0, ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
+        return femfct_enqueue_strip_cheb(ctx, pl, b, nullptr, nullptr, y_out, 1, iters, om.data(), md_scale, ctx->d_y0,
+                                         ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
+    }
     double* buf[3] = {ctx->d_y0, ctx->d_y1, ctx->d_y2};
     int n = ctx->n, W = ctx->W;
     for (int k = 1; k <= iters; ++k) {
@@ -424,7 +481,7 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
         const double* mid = (k >= 2) ? buf[(k - 1) % 3] : nullptr;
         const double* old = (k >= 3) ? buf[(k - 2) % 3] : nullptr;
         double* out = (k == iters) ? y_out : buf[k % 3];
-        LAUNCH_W(KC_CHEB, k_cheb, g, ctx->stream, n, W, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale);
+        LAUNCH_W(KC_CHEB, k_cheb, g, ctx->stream, n, W, ctx->N, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale);
     }
     return FEMFCT_OK;
 }
@@ -436,19 +493,38 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     LaunchGeom g = femfct_geom(ctx, batch);
     hipStream_t st = ctx->stream;
     int n = ctx->n, W = ctx->W;
-    LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n, rhs_bstride,
+    LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n, rhs_bstride,
              u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
-    for (int s = 0; s < budget; ++s)
-        LAUNCH_W(KC_JACOBI, k_jacobi, g, st, n, W, ctx->d_cols, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, ctx->d_part,
-                 ctx->d_ctl, s, ctx->rel_tol);
+    StripPlan pl;
+    TilePlan tp;
+    const bool tiles = femfct_tile_plan(ctx, &tp);
+    const bool strips = !tiles && femfct_strip_plan(ctx, &pl);
+    int units = budget, part_count = 0, ipu = 1;
+    if (tiles) {
+        units = (budget + tp.K - 1) / tp.K;
+        part_count = tp.tiles * tp.tiles;
+        ipu = tp.K;
+        for (int s = 0; s < units; ++s)
+            femfct_enqueue_tile_jacobi(ctx, tp, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
+    } else if (strips) {
+        units = (budget + pl.K - 1) / pl.K;
+        part_count = pl.S;
+        ipu = pl.K;
+        for (int s = 0; s < units; ++s)
+            femfct_enqueue_strip_jacobi(ctx, pl, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
+    } else {
+        for (int s = 0; s < budget; ++s)
+            LAUNCH_W(KC_JACOBI, k_jacobi, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb,
+                     ctx->d_part, ctx->d_ctl, s, ctx->rel_tol);
+    }
     // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
     double* ulow = ctx->d_b;
-    LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
-             ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, budget, ctx->rel_tol, 1.25, 1.0);
+    LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
+             ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0);
     femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
-    LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt, ctx->d_F,
+    LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt, ctx->d_F,
              ctx->d_rp, ctx->d_rm);
-    LAUNCH_W(KC_LIMIT, k_limit, g, st, n, W, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt, u_out,
+    LAUNCH_W(KC_LIMIT, k_limit, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt, u_out,
              out_bstride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));

@@ -1,0 +1,505 @@
+// Strip-fused multi-sweep kernels (temporal blocking) for the latency regime.
+//
+// On the config meshes (n = 1681 / 6561) a Jacobi sweep or a Chebyshev step moves < 1 MB and costs
+// one dependent kernel boundary (~2.7 us measured) -- the step is launch-latency bound, not
+// bandwidth bound.  These kernels run K sweeps per launch: a 1024-thread workgroup owns R
+// consecutive rows, stages the iterate for its rows plus a halo of K*bw rows (bw = matrix
+// bandwidth, N+1 on the structured mesh in either DoF order) in LDS, keeps its matrix rows
+// (values + LDS-local column offsets) in registers, and sweeps K times with __syncthreads()
+// between sweeps; the region of valid rows shrinks by bw per sweep and still covers the owned rows
+// at the end.  Arithmetic per row is identical to the one-sweep kernels (same operation order),
+// nothing is exchanged between workgroups inside a launch, no atomics: deterministic.
+// Works for any ELL pattern whose bandwidth admits K >= 2 within the LDS/register budget.
+#include "femfct_internal.h"
+#include "device_utils.h"
+
+#include <math.h>
+
+#define STRIP_T 1024
+
+namespace {
+
+struct CheOmegas { double w[8]; };
+
+template <int RPT>
+__global__ void __launch_bounds__(STRIP_T)
+k_strip_jacobi(int n, const int32_t* __restrict__ cols, const double* __restrict__ L_, const double* __restrict__ b_,
+               double* __restrict__ xa_, double* __restrict__ xb_, double* __restrict__ part,
+               StepCtl* __restrict__ ctl_, int launch, int K, int bw, int R, int g_build, double rel_tol) {
+    constexpr int W = 7, EXT = RPT * STRIP_T;
+    extern __shared__ double lds[];
+    __shared__ double smem[32];
+    const int bz = blockIdx.y;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    double bnorm;
+    if (launch == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rmax = reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, gridDim.x, OpMax(), 0.0, smem);
+        if (rmax <= rel_tol * bnorm) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K;
+                ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* b = b_ + voff;
+    const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
+    double* xout = ((launch & 1) ? xa_ : xb_) + voff;
+
+    const int r0 = blockIdx.x * R, r1 = min(n, r0 + R);
+    const int e0 = max(0, r0 - K * bw), e1 = min(n, r1 + K * bw), ext = e1 - e0;
+    double lv[RPT][W];       // lv[r][0] holds 1 / L_ii after loading
+    double dg[RPT];
+    int lc[RPT][W - 1];
+    double bv[RPT];
+    double* cur = lds;
+    double* nxt = lds + EXT;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int li = threadIdx.x + r * STRIP_T;
+        if (li < ext) {
+            const int i = e0 + li;
+            dg[r] = L[i];
+            lv[r][0] = 1.0 / dg[r];
+#pragma unroll
+            for (int s = 1; s < W; ++s) {
+                int64_t idx = (int64_t)s * n + i;
+                lv[r][s] = L[idx];
+                int c = cols[idx] - e0;
+                lc[r][s - 1] = (c >= 0 && c < ext) ? c : li;
+            }
+            bv[r] = b[i];
+            cur[li] = xin[i];
+        }
+    }
+    __syncthreads();
+    double rmax = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int lo = (e0 == 0) ? 0 : (k + 1) * bw;
+        const int hi = (e1 == n) ? ext : ext - (k + 1) * bw;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int li = threadIdx.x + r * STRIP_T;
+            if (li < ext) {
+                const double xi = cur[li];
+                double xn = xi;
+                if (li >= lo && li < hi) {
+                    double acc = bv[r];
+#pragma unroll
+                    for (int s = 1; s < W; ++s) acc -= lv[r][s] * cur[lc[r][s - 1]];
+                    xn = acc * lv[r][0];          // one reciprocal per row and launch instead of K divisions
+                    const int i = e0 + li;
+                    if (k == K - 1 && i >= r0 && i < r1) rmax = fmax(rmax, fabs(acc - dg[r] * xi));
+                }
+                nxt[li] = xn;
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int li = threadIdx.x + r * STRIP_T;
+        const int i = e0 + li;
+        if (li < ext && i >= r0 && i < r1) xout[i] = cur[li];
+    }
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) p[(launch & 1) * FEMFCT_MAX_PARTIALS + blockIdx.x] = rmax;
+}
+
+// Chebyshev semi-iteration steps k0..k1-1 (1-based iteration numbers as in helpers.py:175):
+//   y_k = w_k ( (b - M y_{k-1}) / Md + y_{k-1} - y_{k-2} ) + y_{k-2}
+// in: y_{k0-1} (mid, null = 0), y_{k0-2} (old, null = 0); out: y_{k1-1} (mid) and y_{k1-2} (old, optional)
+template <int RPT>
+__global__ void __launch_bounds__(STRIP_T)
+k_strip_cheb(int n, const int32_t* __restrict__ cols, const double* __restrict__ M, const double* __restrict__ b_,
+             const double* __restrict__ ymid_, const double* __restrict__ yold_, double* __restrict__ omid_,
+             double* __restrict__ oold_, int k0, int k1, CheOmegas om, double md_scale, int bw, int R) {
+    constexpr int W = 7, EXT = RPT * STRIP_T;
+    extern __shared__ double lds[];
+    const int64_t voff = (int64_t)blockIdx.y * n;
+    const double* b = b_ + voff;
+    const double* ymid = ymid_ ? ymid_ + voff : nullptr;
+    const double* yold = yold_ ? yold_ + voff : nullptr;
+    double* omid = omid_ + voff;
+    double* oold = oold_ ? oold_ + voff : nullptr;
+    const int K = k1 - k0;
+    const int r0 = blockIdx.x * R, r1 = min(n, r0 + R);
+    const int e0 = max(0, r0 - K * bw), e1 = min(n, r1 + K * bw), ext = e1 - e0;
+    double mv[RPT][W];
+    double rmd[RPT];         // 1 / (md_scale * M_ii)
+    int lc[RPT][W - 1];
+    double bv[RPT];
+    double* y_old = lds;
+    double* y_mid = lds + EXT;
+    double* y_new = lds + 2 * EXT;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int li = threadIdx.x + r * STRIP_T;
+        if (li < ext) {
+            const int i = e0 + li;
+            mv[r][0] = M[i];
+#pragma unroll
+            for (int s = 1; s < W; ++s) {
+                int64_t idx = (int64_t)s * n + i;
+                mv[r][s] = M[idx];
+                int c = cols[idx] - e0;
+                lc[r][s - 1] = (c >= 0 && c < ext) ? c : li;
+            }
+            bv[r] = b[i];
+            rmd[r] = 1.0 / (md_scale * mv[r][0]);
+            y_mid[li] = ymid ? ymid[i] : 0.0;
+            y_old[li] = yold ? yold[i] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const int lo = (e0 == 0) ? 0 : (k + 1) * bw;
+        const int hi = (e1 == n) ? ext : ext - (k + 1) * bw;
+        const double omega = om.w[k];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int li = threadIdx.x + r * STRIP_T;
+            if (li < ext) {
+                const double ym = y_mid[li];
+                double yn = ym;
+                if (li >= lo && li < hi) {
+                    double acc = mv[r][0] * ym;
+#pragma unroll
+                    for (int s = 1; s < W; ++s) acc += mv[r][s] * y_mid[lc[r][s - 1]];
+                    const double rr = bv[r] - acc;
+                    const double z = rr * rmd[r];
+                    const double yo = y_old[li];
+                    yn = omega * (z + ym - yo) + yo;
+                }
+                y_new[li] = yn;
+            }
+        }
+        __syncthreads();
+        double* t = y_old; y_old = y_mid; y_mid = y_new; y_new = t;
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int li = threadIdx.x + r * STRIP_T;
+        const int i = e0 + li;
+        if (li < ext && i >= r0 && i < r1) {
+            omid[i] = y_mid[li];
+            if (oold) oold[i] = y_old[li];
+        }
+    }
+}
+
+template <int RPT>
+void launch_jacobi(femfct_ctx* ctx, dim3 grid, size_t lds, const double* L, const double* b, double* xa, double* xb,
+                   int launch, int K, int bw, int R, int g_build) {
+    hipLaunchKernelGGL((k_strip_jacobi<RPT>), grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->d_cols, L, b, xa, xb,
+                       ctx->d_part, ctx->d_ctl, launch, K, bw, R, g_build, ctx->rel_tol);
+}
+
+template <int RPT>
+void launch_cheb(femfct_ctx* ctx, dim3 grid, size_t lds, const double* b, const double* ymid, const double* yold,
+                 double* omid, double* oold, int k0, int k1, const CheOmegas& om, double md_scale, int bw, int R) {
+    hipLaunchKernelGGL((k_strip_cheb<RPT>), grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->d_cols, ctx->d_M, b, ymid,
+                       yold, omid, oold, k0, k1, om, md_scale, bw, R);
+}
+
+}  // namespace
+
+// Plan: K sweeps per launch, R owned rows per workgroup, RPT rows per thread.  Returns false when
+// the pattern's bandwidth leaves no room for K >= 2 (large meshes: the bandwidth-bound kernels win).
+bool femfct_strip_plan(const femfct_ctx* ctx, StripPlan* pl) {
+    if (!ctx->use_strips || ctx->W != 7 || ctx->bandwidth <= 0) return false;
+    const int bw = ctx->bandwidth;
+    int K = 1300 / bw;
+    if (K > 8) K = 8;
+    if (ctx->strip_k > 0) K = std::min(ctx->strip_k, 1800 / bw);   // tuning knob (FEMFCT_STRIP_K)
+    if (K > 8) K = 8;
+    if (K < 2) return false;
+    const int halo = K * bw;
+    // fewest rows per thread that still leave >= 256 owned rows, then the largest R for that
+    int rpt = (2 * halo + 256 + STRIP_T - 1) / STRIP_T;
+    if (rpt < 2) rpt = 2;
+    if (rpt > 4) return false;
+    int R = rpt * STRIP_T - 2 * halo;
+    if (R > ctx->n) R = ctx->n;
+    pl->K = K; pl->R = R; pl->bw = bw; pl->rpt = rpt;
+    pl->S = (ctx->n + R - 1) / R;
+    return true;
+}
+
+int femfct_strip_init(femfct_ctx* ctx) {
+    // > 64 KB of dynamic LDS needs the attribute
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_strip_cheb<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * STRIP_T * 8));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_strip_cheb<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * STRIP_T * 8));
+    return FEMFCT_OK;
+}
+
+int femfct_enqueue_strip_jacobi(femfct_ctx* ctx, const StripPlan& pl, const double* L, const double* b, double* xa,
+                                double* xb, int launch, int g_build, int32_t batch) {
+    dim3 grid(pl.S, batch, 1);
+    size_t lds = (size_t)2 * pl.rpt * STRIP_T * 8;
+    femfct_prof_begin(ctx, KC_JACOBI);
+    switch (pl.rpt) {
+        case 2: launch_jacobi<2>(ctx, grid, lds, L, b, xa, xb, launch, pl.K, pl.bw, pl.R, g_build); break;
+        case 3: launch_jacobi<3>(ctx, grid, lds, L, b, xa, xb, launch, pl.K, pl.bw, pl.R, g_build); break;
+        default: launch_jacobi<4>(ctx, grid, lds, L, b, xa, xb, launch, pl.K, pl.bw, pl.R, g_build); break;
+    }
+    femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
+// Chebyshev iterations k_first..k_last (1-based, inclusive) in ceil(count/K) launches.
+// in_mid = y_{k_first-1} (null = 0), in_old = y_{k_first-2} (null = 0); result y_{k_last} -> y_out.
+// pairs (bufA0,bufA1)/(bufB0,bufB1) are alternated as intermediate (mid, old) storage.
+int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double* b, const double* in_mid,
+                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
+                              double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1,
+                              int32_t batch) {
+    dim3 grid(pl.S, batch, 1);
+    size_t lds = (size_t)3 * pl.rpt * STRIP_T * 8;
+    const double* mid = in_mid;
+    const double* old = in_old;
+    int which = 0;
+    for (int k0 = k_first; k0 <= k_last; k0 += pl.K) {
+        int k1 = std::min(k_last + 1, k0 + pl.K);
+        CheOmegas om;
+        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas[k - 1];
+        const bool last = (k1 == k_last + 1);
+        double* omid = last ? y_out : (which ? bufB0 : bufA0);
+        double* oold = last ? nullptr : (which ? bufB1 : bufA1);
+        femfct_prof_begin(ctx, KC_CHEB);
+        switch (pl.rpt) {
+            case 2: launch_cheb<2>(ctx, grid, lds, b, mid, old, omid, oold, k0, k1, om, md_scale, pl.bw, pl.R); break;
+            case 3: launch_cheb<3>(ctx, grid, lds, b, mid, old, omid, oold, k0, k1, om, md_scale, pl.bw, pl.R); break;
+            default: launch_cheb<4>(ctx, grid, lds, b, mid, old, omid, oold, k0, k1, om, md_scale, pl.bw, pl.R); break;
+        }
+        femfct_prof_end(ctx);
+        mid = omid;
+        old = oold;
+        which ^= 1;
+    }
+    return FEMFCT_OK;
+}
+
+// ===========================================================================================
+// 2-D tile variants for the structured mesh in vertex order: a 1024-thread workgroup owns a
+// 16 x 16 tile and stages a 32 x 32 patch (halo 8 on every side) -- one node per thread, the
+// node's matrix row in registers, the iterate in LDS -- and runs up to 8 sweeps per launch.
+// Compared with row strips the patch is 1/2 .. 1/3 the rows per workgroup for the same K, there
+// is no column table to load, and 36 workgroups (81 x 81 mesh) share the work instead of 9.
+// ===========================================================================================
+#define TILE_T 16
+#define TILE_H 8
+#define TILE_L 32
+#define TILE_LD 33   // padded LDS row
+
+namespace {
+
+struct TileGeom {
+    int lx, ly, gx, gy, i;
+    bool inside, owned;
+    int kvalid;          // the node's value is exact for sweeps k < kvalid
+    int nb[6];           // LDS offsets of the six neighbours (clamped into the patch)
+    int self;
+};
+
+__device__ __forceinline__ TileGeom tile_geom(int N) {
+    TileGeom g;
+    g.lx = threadIdx.x & (TILE_L - 1);
+    g.ly = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * TILE_T - TILE_H, y0 = blockIdx.y * TILE_T - TILE_H;
+    g.gx = x0 + g.lx;
+    g.gy = y0 + g.ly;
+    g.inside = g.gx >= 0 && g.gx < N && g.gy >= 0 && g.gy < N;
+    g.i = g.inside ? g.gy * N + g.gx : 0;
+    g.owned = g.inside && g.lx >= TILE_H && g.lx < TILE_H + TILE_T && g.ly >= TILE_H && g.ly < TILE_H + TILE_T;
+    int kv = 1 << 20;
+    if (x0 > 0) kv = min(kv, g.lx);
+    if (x0 + TILE_L - 1 < N - 1) kv = min(kv, TILE_L - 1 - g.lx);
+    if (y0 > 0) kv = min(kv, g.ly);
+    if (y0 + TILE_L - 1 < N - 1) kv = min(kv, TILE_L - 1 - g.ly);
+    g.kvalid = g.inside ? kv : 0;
+    const int dx[6] = {1, 1, 0, -1, -1, 0}, dy[6] = {0, 1, 1, 0, -1, -1};
+    g.self = g.ly * TILE_LD + g.lx;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        int nx = min(max(g.lx + dx[s], 0), TILE_L - 1), ny = min(max(g.ly + dy[s], 0), TILE_L - 1);
+        g.nb[s] = ny * TILE_LD + nx;
+    }
+    return g;
+}
+
+__global__ void __launch_bounds__(STRIP_T)
+k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
+              double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
+              int g_build, double rel_tol) {
+    constexpr int W = 7;
+    __shared__ double xs[2][TILE_L * TILE_LD];
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    double bnorm;
+    if (launch == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        if (wg == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rmax = reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        if (rmax <= rel_tol * bnorm) {
+            if (wg == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K;
+                ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
+    double* xout = ((launch & 1) ? xa_ : xb_) + voff;
+    const TileGeom g = tile_geom(N);
+    double lv[W - 1], dg = 1.0, rdg = 1.0, bv = 0.0, xi = 0.0;
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) lv[s] = 0.0;
+    if (g.inside) {
+        dg = L[g.i];
+        rdg = 1.0 / dg;
+#pragma unroll
+        for (int s = 1; s < W; ++s) lv[s - 1] = L[(int64_t)s * n + g.i];
+        bv = b_[voff + g.i];
+        xi = xin[g.i];
+    }
+    xs[0][g.self] = xi;
+    __syncthreads();
+    double rmax = 0.0;
+    int cur = 0;
+    for (int k = 0; k < K; ++k) {
+        const double* c = xs[cur];
+        double xn = c[g.self];
+        if (k < g.kvalid) {
+            double acc = bv;
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+            if (k == K - 1 && g.owned) rmax = fmax(rmax, fabs(acc - dg * xn));
+            xn = acc * rdg;
+        }
+        xs[cur ^ 1][g.self] = xn;
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (g.owned) xout[g.i] = xs[cur][g.self];
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+}
+
+__global__ void __launch_bounds__(STRIP_T)
+k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
+            const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
+            CheOmegas om, double md_scale) {
+    constexpr int W = 7;
+    __shared__ double ys[3][TILE_L * TILE_LD];
+    const int64_t voff = (int64_t)blockIdx.z * n;
+    const TileGeom g = tile_geom(N);
+    double mv[W - 1], md = 1.0, rmd = 1.0, bv = 0.0, ym = 0.0, yo = 0.0;
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) mv[s] = 0.0;
+    if (g.inside) {
+        md = M[g.i];
+        rmd = 1.0 / (md_scale * md);
+#pragma unroll
+        for (int s = 1; s < W; ++s) mv[s - 1] = M[(int64_t)s * n + g.i];
+        bv = b_[voff + g.i];
+        if (ymid_) ym = ymid_[voff + g.i];
+        if (yold_) yo = yold_[voff + g.i];
+    }
+    ys[0][g.self] = yo;
+    ys[1][g.self] = ym;
+    __syncthreads();
+    int io = 0, im = 1, in_ = 2;
+    for (int k = 0; k < K; ++k) {
+        const double* ymd = ys[im];
+        const double ymv = ymd[g.self];
+        double yn = ymv;
+        if (k < g.kvalid) {
+            double acc = md * ymv;
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
+            const double z = (bv - acc) * rmd;
+            const double yov = ys[io][g.self];
+            yn = om.w[k] * (z + ymv - yov) + yov;
+        }
+        ys[in_][g.self] = yn;
+        __syncthreads();
+        int t = io; io = im; im = in_; in_ = t;
+    }
+    if (g.owned) {
+        omid_[voff + g.i] = ys[im][g.self];
+        if (oold_) oold_[voff + g.i] = ys[io][g.self];
+    }
+}
+
+}  // namespace
+
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl) {
+    if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
+    const int t = (ctx->N + TILE_T - 1) / TILE_T;
+    if ((int64_t)t * t > FEMFCT_MAX_PARTIALS) return false;
+    pl->tiles = t;
+    pl->K = TILE_H;
+    if (ctx->strip_k > 0 && ctx->strip_k < TILE_H) pl->K = ctx->strip_k;
+    return true;
+}
+
+int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
+                               double* xb, int launch, int g_build, int32_t batch) {
+    femfct_prof_begin(ctx, KC_JACOBI);
+    hipLaunchKernelGGL(k_tile_jacobi, dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,
+                       xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol);
+    femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
+int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
+                             const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
+                             double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch) {
+    const double* mid = in_mid;
+    const double* old = in_old;
+    int which = 0;
+    for (int k0 = k_first; k0 <= k_last; k0 += pl.K) {
+        int k1 = std::min(k_last + 1, k0 + pl.K);
+        CheOmegas om;
+        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas[k - 1];
+        const bool last = (k1 == k_last + 1);
+        double* omid = last ? y_out : (which ? bufB0 : bufA0);
+        double* oold = last ? nullptr : (which ? bufB1 : bufA1);
+        femfct_prof_begin(ctx, KC_CHEB);
+        hipLaunchKernelGGL(k_tile_cheb, dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
+                           ctx->d_M, b, mid, old, omid, oold, k1 - k0, om, md_scale);
+        femfct_prof_end(ctx);
+        mid = omid;
+        old = oold;
+        which ^= 1;
+    }
+    return FEMFCT_OK;
+}

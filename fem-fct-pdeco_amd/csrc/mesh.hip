@@ -8,6 +8,7 @@
 #include "stencil.h"
 
 #include <algorithm>
+#include <stdlib.h>
 
 int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vector<int32_t>& cols,
                            const std::vector<uint8_t>& tslot);
@@ -65,6 +66,8 @@ extern "C" int femfct_set_mesh_square(femfct_ctx* ctx, double a1, double a2, int
     int rc = femfct_install_pattern(ctx, n, STENCIL_W, cols, tslot);
     if (rc != FEMFCT_OK) return rc;
     ctx->structured = true;
+    ctx->implicit_cols = (order == FEMFCT_ORDER_VERTEX);
+    if (const char* e = getenv("FEMFCT_IMPLICIT")) ctx->implicit_cols = ctx->implicit_cols && atoi(e) != 0;
     ctx->a1 = a1; ctx->a2 = a2; ctx->n_cells = n_cells; ctx->N = (int32_t)N; ctx->order = order;
     ctx->h = (a2 - a1) / n_cells;
     if (order == FEMFCT_ORDER_FENICS) {

@@ -123,7 +123,7 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
             return FEMFCT_OK;
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, 0, false, begin, step);
+    return femfct_run_sweep(ctx, 2, num_steps, batch, 0, false, begin, step);
 }
 
 int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
@@ -168,7 +168,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
             return FEMFCT_OK;
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, num_steps - 1, false, begin, step);
+    return femfct_run_sweep(ctx, 3, num_steps, batch, num_steps - 1, false, begin, step);
 }
 
 // per-step solver diagnostics of the most recent trajectory sweep: info[step*batch + b]

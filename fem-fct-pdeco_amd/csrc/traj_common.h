@@ -27,11 +27,15 @@ static inline int femfct_round_kry_budget(const femfct_ctx* ctx, int b) {
 // logs; if a sweep/iteration budget was too small anywhere the whole sweep is repeated with a
 // larger one (the sweep's inputs are never overwritten, so a repeat is exact).
 template <class Begin, class Step>
-int femfct_run_sweep(femfct_ctx* ctx, int32_t num_steps, int32_t batch, int level0, bool krylov, Begin&& begin,
-                     Step&& step) {
+int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch, int level0, bool krylov,
+                     Begin&& begin, Step&& step) {
+    // budgets are remembered per kind of sweep: the forward and the adjoint operator of a problem
+    // need different sweep counts, and a shared budget would make them evict each other
+    if (!ctx->kind_budget.count(kind)) ctx->kind_budget[kind] = 48;
+    if (!ctx->kind_kbudget.count(kind)) ctx->kind_kbudget[kind] = 40;
     for (;;) {
-        const int budget = femfct_round_budget(ctx, ctx->sweep_budget);
-        const int kbudget = femfct_round_kry_budget(ctx, ctx->kry_budget);
+        const int budget = femfct_round_budget(ctx, ctx->kind_budget[kind]);
+        const int kbudget = femfct_round_kry_budget(ctx, ctx->kind_kbudget[kind]);
         int rc = begin();
         if (rc != FEMFCT_OK) return rc;
         int32_t init[2] = {level0, 0};
@@ -71,8 +75,8 @@ int femfct_run_sweep(femfct_ctx* ctx, int32_t num_steps, int32_t batch, int leve
             }
         }
         if (!short_budget && !kshort) {
-            ctx->sweep_budget = std::min(ctx->max_iters, std::max(8, worst + worst / 8 + 2));
-            if (krylov) ctx->kry_budget = std::min(ctx->kry_max_iters, std::max(8, kworst + kworst / 4 + 2));
+            ctx->kind_budget[kind] = femfct_next_budget(ctx, worst);
+            if (krylov) ctx->kind_kbudget[kind] = std::min(ctx->kry_max_iters, std::max(8, kworst + kworst / 4 + 2));
             return FEMFCT_OK;
         }
         if (short_budget) {
@@ -80,14 +84,14 @@ int femfct_run_sweep(femfct_ctx* ctx, int32_t num_steps, int32_t batch, int leve
                 return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
                                    "low-order solve: residual %.3e after %d Jacobi sweeps (tol %.1e)", worst_res,
                                    budget, ctx->rel_tol);
-            ctx->sweep_budget = std::min(ctx->max_iters, budget * 2);
+            ctx->kind_budget[kind] = femfct_grow_budget(ctx, budget);
         }
         if (kshort) {
             if (kbudget >= ctx->kry_max_iters)
                 return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
                                    "BiCGStab: residual %.3e after %d iterations (tol %.1e)", kworst_res, kbudget,
                                    ctx->kry_tol);
-            ctx->kry_budget = std::min(ctx->kry_max_iters, kbudget * 2);
+            ctx->kind_kbudget[kind] = std::min(ctx->kry_max_iters, kbudget * 2);
         }
     }
 }

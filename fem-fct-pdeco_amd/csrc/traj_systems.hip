@@ -149,7 +149,7 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
             return femfct_enqueue_step_end(ctx, 1, batch, false);
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, 0, false, begin, step);
+    return femfct_run_sweep(ctx, 10, num_steps, batch, 0, false, begin, step);
 }
 
 // helpers.py:968-1038: p(T) = uhat_T - u(T); FCT_alg_ref(-Mat_p, 0, p_{n+1}, non_flux_mat = M_u2(u_n) - M)
@@ -179,7 +179,7 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
             return femfct_enqueue_step_end(ctx, -1, batch, false);
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, num_steps - 1, false, begin, step);
+    return femfct_run_sweep(ctx, 11, num_steps, batch, num_steps - 1, false, begin, step);
 }
 
 // ------------------------------------------------------------------ advective Schnakenberg
@@ -231,7 +231,7 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
             return femfct_enqueue_step_end(ctx, 1, batch, true);
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, 0, true, begin, step);
+    return femfct_run_sweep(ctx, 12, num_steps, batch, 0, true, begin, step);
 }
 
 // helpers.py:599-698.  AwT_ell = assemble_sparse(dot(wind,grad(u))*w*dx) = transpose of Aw.
@@ -286,7 +286,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
             return femfct_enqueue_step_end(ctx, -1, batch, true);
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, num_steps - 1, true, begin, step);
+    return femfct_run_sweep(ctx, 13, num_steps, batch, num_steps - 1, true, begin, step);
 }
 
 // ------------------------------------------------------------------ chemotaxis
@@ -326,7 +326,7 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
             return femfct_enqueue_step_end(ctx, 1, batch, true);
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, 0, true, begin, step);
+    return femfct_run_sweep(ctx, 14, num_steps, batch, 0, true, begin, step);
 }
 
 // helpers.py:1387-1581.  alltime = 0: optim == "finaltime" (uhat/vhat: n doubles per member, terminal
@@ -381,7 +381,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
             return femfct_enqueue_step_end(ctx, -1, batch, true);
         });
     };
-    return femfct_run_sweep(ctx, num_steps, batch, num_steps - 1, true, begin, step);
+    return femfct_run_sweep(ctx, 15, num_steps, batch, num_steps - 1, true, begin, step);
 }
 
 // BiCGStab diagnostics of the most recent sweep that used it: info_host[step*batch + b]
