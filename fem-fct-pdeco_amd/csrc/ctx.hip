@@ -70,6 +70,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_b); dev_free(&ctx->d_xa); dev_free(&ctx->d_xb);
     dev_free(&ctx->d_du); dev_free(&ctx->d_y0); dev_free(&ctx->d_y1); dev_free(&ctx->d_y2); dev_free(&ctx->d_rdu);
     dev_free(&ctx->d_rp); dev_free(&ctx->d_rm); dev_free(&ctx->d_part); dev_free(&ctx->d_ctl);
+    dev_free(&ctx->d_bigpart); ctx->bigpart_count = 0;
     dev_free(&ctx->d_hA); dev_free(&ctx->d_hN); dev_free(&ctx->d_hrhs); dev_free(&ctx->d_hu);
     dev_free(&ctx->d_hout); dev_free(&ctx->d_hcsr);
     femfct_mesh_release(ctx);
@@ -117,6 +118,14 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     A_(d_rdu, nv); A_(d_rp, nv); A_(d_rm, nv);
     A_(d_part, (size_t)batch * 4 * FEMFCT_MAX_PARTIALS);
     A_(d_ctl, (size_t)batch);
+    {
+        TilePlan tp;
+        ctx->bigpart_count = 0;
+        if (femfct_tile_plan(ctx, &tp, false) && femfct_tile_big(ctx, tp)) {
+            ctx->bigpart_count = (int64_t)tp.tiles * tp.tiles;
+            A_(d_bigpart, (size_t)batch * ctx->bigpart_count);
+        }
+    }
 #undef A_
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctl, 0, sizeof(StepCtl) * batch, ctx->stream));
     ctx->ws_batch = batch;
@@ -125,7 +134,7 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
 
 int femfct_fused_k(const femfct_ctx* ctx) {
     TilePlan tp;
-    if (femfct_tile_plan(ctx, &tp)) return tp.K;
+    if (femfct_tile_plan(ctx, &tp, false)) return tp.K;
     StripPlan pl;
     if (femfct_strip_plan(ctx, &pl)) return pl.K;
     return 1;
@@ -255,6 +264,17 @@ int femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters
     ctx->max_iters = max_iters;
     if (ctx->sweep_budget > max_iters) ctx->sweep_budget = max_iters;
     femfct_drop_graphs(ctx);
+    return FEMFCT_OK;
+}
+
+int femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles) {
+    ARG_TRY(ctx, ctx, "null ctx");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->use_strips = strips != 0;
+    ctx->use_tiles = tiles != 0;
+    femfct_drop_graphs(ctx);
+    ctx->kind_budget.clear();
+    ctx->ws_batch = 0;   // re-plan the workspace (big partial buffer) on the next call
     return FEMFCT_OK;
 }
 

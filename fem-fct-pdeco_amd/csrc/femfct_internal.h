@@ -27,6 +27,7 @@ struct StepCtl {
     double  resid;        // ||r||_inf / ||b||_inf seen by the last active sweep
     double  bnorm;        // ||b||_inf
     double  min_rowsum;   // min_i rowsum(L)
+    double  rs[2];        // residual max of fused launch j at [j & 1] when a separate reduce kernel is used
     double  pad;
 };
 
@@ -75,6 +76,8 @@ struct femfct_ctx {
     double *d_rp = nullptr, *d_rm = nullptr;                          // R+ / R- [B*n]
     double *d_part = nullptr;                                         // block partials [B*4*MAX_PARTIALS]
     StepCtl* d_ctl = nullptr;                                         // [B]
+    double* d_bigpart = nullptr;     // [B * bigpart_count] residual partials of fused launches on large grids
+    int64_t bigpart_count = 0;
     // host staging for the *_host convenience calls
     double *d_hA = nullptr, *d_hN = nullptr, *d_hrhs = nullptr, *d_hu = nullptr, *d_hout = nullptr, *d_hcsr = nullptr;
 
@@ -155,12 +158,15 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
                               double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1,
                               int32_t batch);
 struct TilePlan { int tiles, K; };
-bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl);
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true);
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
                                double* xb, int launch, int g_build, int32_t batch);
+bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl);   // more workgroups than in-kernel partials
 int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
                              double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch);
+int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
+                                   struct VecRef out, int64_t out_bstride, int32_t batch);
 // number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
 int femfct_fused_k(const femfct_ctx* ctx);
 // sweep-budget policy (sweeps to enqueue for the next step sequence)

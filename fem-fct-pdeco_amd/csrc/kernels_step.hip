@@ -201,7 +201,8 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int
 __device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, int budget, int iters_per_unit,
                                                double rel_tol, double* smem) {
     if (ctl->done) return;
-    double rmax = reduce_partials(p + ((budget - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
+    double rmax = (G < 0) ? ctl->rs[(budget - 1) & 1]
+                          : reduce_partials(p + ((budget - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
     // every block computes the same values; block 0 publishes them for later kernels' diagnostics.
     // parity is derived locally below (ctl->parity is only written here by block 0 and read by
     // later kernels, never by other blocks of this kernel).
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     // solution buffer: decided by the sweep that detected convergence, else by the budget parity
     const int parity = ctl->done ? ctl->parity : (budget & 1);
-    finalize_solve(ctl, p, part_count ? part_count : gridDim.x, budget, iters_per_unit, rel_tol, smem);
+    finalize_solve(ctl, p, part_count ? part_count : (int)gridDim.x, budget, iters_per_unit, rel_tol, smem);
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const double* A = A_ + moff;
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -458,7 +459,7 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
     cheb_omegas(iters, lmin, lmax, om);
     const double md_scale = (lmin + lmax) / 2.0;
     TilePlan tp;
-    if (femfct_tile_plan(ctx, &tp)) {
+    if (femfct_tile_plan(ctx, &tp, false)) {
         if (first_done_in_y1)
             return femfct_enqueue_tile_cheb(ctx, tp, b, ctx->d_y1, nullptr, y_out, 2, iters, om.data(), md_scale,
                                             ctx->d_y0, ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
@@ -497,12 +498,14 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
              u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
     StripPlan pl;
     TilePlan tp;
-    const bool tiles = femfct_tile_plan(ctx, &tp);
+    // Jacobi tiles: small grids reduce the residual partials in the consumer; large grids use the
+    // extra reduce kernel (needs the big partial buffer, allocated by femfct_ensure_workspace)
+    const bool tiles = femfct_tile_plan(ctx, &tp, false) && (!femfct_tile_big(ctx, tp) || ctx->d_bigpart);
     const bool strips = !tiles && femfct_strip_plan(ctx, &pl);
     int units = budget, part_count = 0, ipu = 1;
     if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
-        part_count = tp.tiles * tp.tiles;
+        part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
         ipu = tp.K;
         for (int s = 0; s < units; ++s)
             femfct_enqueue_tile_jacobi(ctx, tp, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
@@ -522,10 +525,14 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
              ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0);
     femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
-    LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt, ctx->d_F,
-             ctx->d_rp, ctx->d_rm);
-    LAUNCH_W(KC_LIMIT, k_limit, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt, u_out,
-             out_bstride);
+    if (tiles) {
+        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch);
+    } else {
+        LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt,
+                 ctx->d_F, ctx->d_rp, ctx->d_rm);
+        LAUNCH_W(KC_LIMIT, k_limit, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_F, ctx->d_rp, ctx->d_rm, ulow, ctx->d_ml, dt,
+                 u_out, out_bstride);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return FEMFCT_OK;

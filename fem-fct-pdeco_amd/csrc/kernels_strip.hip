@@ -316,28 +316,31 @@ struct TileGeom {
     int self;
 };
 
+template <int T = TILE_T, int H = TILE_H, int PL = TILE_L>
 __device__ __forceinline__ TileGeom tile_geom(int N) {
+    static_assert(T + 2 * H == PL, "patch edge = tile + 2 halos");
+    constexpr int PLD = PL + 1;
     TileGeom g;
-    g.lx = threadIdx.x & (TILE_L - 1);
-    g.ly = threadIdx.x >> 5;
-    const int x0 = blockIdx.x * TILE_T - TILE_H, y0 = blockIdx.y * TILE_T - TILE_H;
+    g.lx = threadIdx.x % PL;
+    g.ly = threadIdx.x / PL;
+    const int x0 = blockIdx.x * T - H, y0 = blockIdx.y * T - H;
     g.gx = x0 + g.lx;
     g.gy = y0 + g.ly;
     g.inside = g.gx >= 0 && g.gx < N && g.gy >= 0 && g.gy < N;
     g.i = g.inside ? g.gy * N + g.gx : 0;
-    g.owned = g.inside && g.lx >= TILE_H && g.lx < TILE_H + TILE_T && g.ly >= TILE_H && g.ly < TILE_H + TILE_T;
+    g.owned = g.inside && g.lx >= H && g.lx < H + T && g.ly >= H && g.ly < H + T;
     int kv = 1 << 20;
     if (x0 > 0) kv = min(kv, g.lx);
-    if (x0 + TILE_L - 1 < N - 1) kv = min(kv, TILE_L - 1 - g.lx);
+    if (x0 + PL - 1 < N - 1) kv = min(kv, PL - 1 - g.lx);
     if (y0 > 0) kv = min(kv, g.ly);
-    if (y0 + TILE_L - 1 < N - 1) kv = min(kv, TILE_L - 1 - g.ly);
+    if (y0 + PL - 1 < N - 1) kv = min(kv, PL - 1 - g.ly);
     g.kvalid = g.inside ? kv : 0;
     const int dx[6] = {1, 1, 0, -1, -1, 0}, dy[6] = {0, 1, 1, 0, -1, -1};
-    g.self = g.ly * TILE_LD + g.lx;
+    g.self = g.ly * PLD + g.lx;
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        int nx = min(max(g.lx + dx[s], 0), TILE_L - 1), ny = min(max(g.ly + dy[s], 0), TILE_L - 1);
-        g.nb[s] = ny * TILE_LD + nx;
+        int nx = min(max(g.lx + dx[s], 0), PL - 1), ny = min(max(g.ly + dy[s], 0), PL - 1);
+        g.nb[s] = ny * PLD + nx;
     }
     return g;
 }
@@ -345,7 +348,7 @@ __device__ __forceinline__ TileGeom tile_geom(int N) {
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
               double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-              int g_build, double rel_tol) {
+              int g_build, double rel_tol, double* __restrict__ bigpart) {
     constexpr int W = 7;
     __shared__ double xs[2][TILE_L * TILE_LD];
     __shared__ double smem[32];
@@ -365,7 +368,8 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
         }
     } else {
         bnorm = ctl->bnorm;
-        double rmax = reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        double rmax = bigpart ? ctl->rs[(launch - 1) & 1]
+                              : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (wg == 0 && threadIdx.x == 0) {
                 ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K;
@@ -378,7 +382,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     const double* L = L_ + moff;
     const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
     double* xout = ((launch & 1) ? xa_ : xb_) + voff;
-    const TileGeom g = tile_geom(N);
+    const TileGeom g = tile_geom<>(N);
     double lv[W - 1], dg = 1.0, rdg = 1.0, bv = 0.0, xi = 0.0;
 #pragma unroll
     for (int s = 0; s < W - 1; ++s) lv[s] = 0.0;
@@ -410,7 +414,23 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     }
     if (g.owned) xout[g.i] = xs[cur][g.self];
     rmax = block_reduce(rmax, OpMax(), 0.0, smem);
-    if (threadIdx.x == 0) p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+    if (threadIdx.x == 0) {
+        if (bigpart) bigpart[(int64_t)bz * nwg + wg] = rmax;
+        else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+    }
+}
+
+// one block per batch member: max over the residual partials of a fused launch on a large grid
+__global__ void __launch_bounds__(STRIP_T)
+k_reduce_resid(const double* __restrict__ bigpart, int64_t count, StepCtl* __restrict__ ctl_, int launch) {
+    __shared__ double smem[32];
+    const int bz = blockIdx.x;
+    if (ctl_[bz].done) return;
+    const double* q = bigpart + (int64_t)bz * count;
+    double v = 0.0;
+    for (int64_t k = threadIdx.x; k < count; k += blockDim.x) v = fmax(v, q[k]);
+    v = block_reduce(v, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) ctl_[bz].rs[launch & 1] = v;
 }
 
 __global__ void __launch_bounds__(STRIP_T)
@@ -420,7 +440,7 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
     constexpr int W = 7;
     __shared__ double ys[3][TILE_L * TILE_LD];
     const int64_t voff = (int64_t)blockIdx.z * n;
-    const TileGeom g = tile_geom(N);
+    const TileGeom g = tile_geom<>(N);
     double mv[W - 1], md = 1.0, rmd = 1.0, bv = 0.0, ym = 0.0, yo = 0.0;
 #pragma unroll
     for (int s = 0; s < W - 1; ++s) mv[s] = 0.0;
@@ -459,23 +479,108 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
     }
 }
 
+
+// flux + Zalesak limiter + explicit correction in one launch (helpers.py:1818-1870): a 12 x 12
+// tile with a halo of two rings (16 x 16 patch, 256 threads) (R+- of the first ring needs u_L, du/dt of the second);
+// F_ij stays in registers, R+- goes through LDS.
+#define FL_T 12
+#define FL_H 2
+#define FL_L 16
+#define FL_LD 17
+__global__ void __launch_bounds__(FL_L * FL_L)
+k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __restrict__ D_,
+                  const double* __restrict__ ulow_, const double* __restrict__ du_, const double* __restrict__ ml,
+                  double dt, VecRef out_ref, int64_t out_bstride) {
+    constexpr int W = 7;
+    __shared__ double su[FL_L * FL_LD], sd[FL_L * FL_LD], srp[FL_L * FL_LD], srm[FL_L * FL_LD];
+    const int bz = blockIdx.z;
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const TileGeom g = tile_geom<FL_T, FL_H, FL_L>(N);
+    double ui = 0.0, dui = 0.0, mli = 1.0;
+    if (g.inside) { ui = ulow_[voff + g.i]; dui = du_[voff + g.i]; mli = ml[g.i]; }
+    su[g.self] = ui;
+    sd[g.self] = dui;
+    srp[g.self] = 1.0;
+    srm[g.self] = 1.0;
+    __syncthreads();
+    double f[W - 1];
+    // every inside node whose six neighbours are in the patch (or outside the grid) gets its fluxes
+    const bool have = g.inside && g.kvalid >= 1;
+    if (have) {
+        double pp = 0.0, pm = 0.0, umax = ui, umin = ui;
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            const int64_t idx = (int64_t)s * n + g.i;
+            const double uj = su[g.nb[s - 1]];
+            const double fs = M[idx] * (dui - sd[g.nb[s - 1]]) + D_[moff + idx] * (ui - uj);
+            f[s - 1] = fs;
+            pp += fmax(fs, 0.0);
+            pm += fmin(fs, 0.0);
+            // a clamped neighbour (outside the grid) has M = D = 0 and must not enter the bounds:
+            // its LDS slot then aliases a patch node, so take it only when the coefficient is live
+            const bool live = (M[idx] != 0.0) || (D_[moff + idx] != 0.0);
+            umax = live ? fmax(umax, uj) : umax;
+            umin = live ? fmin(umin, uj) : umin;
+        }
+        const double qp = umax - ui, qm = umin - ui;
+        srp[g.self] = (pp != 0.0) ? fmin(1.0, mli * qp / (dt * pp)) : 1.0;
+        srm[g.self] = (pm != 0.0) ? fmin(1.0, mli * qm / (dt * pm)) : 1.0;
+    }
+    __syncthreads();
+    if (g.owned) {
+        const double rpi = srp[g.self], rmi = srm[g.self];
+        double fbar = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) {
+            const double fs = f[s];
+            const double a = (fs > 0.0) ? fmin(rpi, srm[g.nb[s]]) : fmin(rmi, srp[g.nb[s]]);
+            fbar += a * fs;
+        }
+        double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
+        out[g.i] = ui + dt * fbar / mli;
+    }
+}
+
 }  // namespace
 
-bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl) {
+int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
+                                   VecRef out, int64_t out_bstride, int32_t batch) {
+    const int t = (ctx->N + FL_T - 1) / FL_T;
+    femfct_prof_begin(ctx, KC_FLUX);
+    hipLaunchKernelGGL(k_tile_flux_limit, dim3(t, t, batch), dim3(FL_L * FL_L), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
+                       ulow, du, ctx->d_ml, dt, out, out_bstride);
+    femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
+// need_partials: the Jacobi variant publishes one residual partial per workgroup (capped);
+// the Chebyshev variant has no reduction and also serves large meshes, where running 8 iterations
+// per pass over the matrix cuts the HBM traffic per iteration by about half.
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials) {
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
     const int t = (ctx->N + TILE_T - 1) / TILE_T;
-    if ((int64_t)t * t > FEMFCT_MAX_PARTIALS) return false;
+    if (need_partials && (int64_t)t * t > FEMFCT_MAX_PARTIALS) return false;
+    if (t > 65535) return false;
     pl->tiles = t;
     pl->K = TILE_H;
     if (ctx->strip_k > 0 && ctx->strip_k < TILE_H) pl->K = ctx->strip_k;
     return true;
 }
 
+bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl) {
+    return (int64_t)pl.tiles * pl.tiles > FEMFCT_MAX_PARTIALS;
+}
+
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
                                double* xb, int launch, int g_build, int32_t batch) {
+    const bool big = femfct_tile_big(ctx, pl);
     femfct_prof_begin(ctx, KC_JACOBI);
     hipLaunchKernelGGL(k_tile_jacobi, dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,
-                       xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol);
+                       xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol,
+                       big ? ctx->d_bigpart : nullptr);
+    if (big)
+        hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart,
+                           (int64_t)pl.tiles * pl.tiles, ctx->d_ctl, launch);
     femfct_prof_end(ctx);
     return FEMFCT_OK;
 }

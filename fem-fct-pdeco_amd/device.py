@@ -130,6 +130,9 @@ class Context:
         check(self.handle, lib.femfct_profile_report(self.handle, _host_ptr(ms), _host_ptr(cnt), 8))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
+    def set_fusion(self, strips=True, tiles=True):
+        check(self.handle, lib.femfct_set_fusion(self.handle, int(bool(strips)), int(bool(tiles))))
+
     def synchronize(self):
         check(self.handle, lib.femfct_synchronize(self.handle))
 

@@ -79,6 +79,10 @@ int         femfct_synchronize(femfct_ctx* ctx);
 void*       femfct_stream(femfct_ctx* ctx);                 /* hipStream_t */
 int         femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters);
 int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay of the step sequence (default on) */
+/* multi-sweep fusion of the Jacobi / Chebyshev kernels: row strips (any banded pattern) and 2-D tiles
+ * (structured mesh in vertex order); both default on, results agree with the one-sweep kernels to the
+ * solver tolerance.  For tests and tuning. */
+int         femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles);
 
 /* Per-kernel timing with HIP events recorded on the ctx stream around every kernel of the step
  * sequence (used by bench.py for the roofline figures).  While enabled, launches are eager.

@@ -236,3 +236,30 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
     assert rel(c_s, c_prev) < 1e-8 and rel(u_s, uk) < 1e-8
     assert np.array_equal(c_s, c_q) and np.array_equal(u_s, u_q) and h_s["cost"] == h_q["cost"]
     prob.close()
+
+
+@pytest.mark.parametrize("nc,order", [(40, 0), (40, 1), (767, 0)])
+def test_fused_kernels_agree_with_one_sweep_kernels(hp, solvers, nc, order):
+    """Strip / tile multi-sweep kernels (incl. the large-grid tile path with the separate residual
+    reduce kernel at 768 x 768 nodes) against the plain one-sweep kernels on the same inputs."""
+    Nt = 3
+    mesh = hp.SquareMeshP1(-1, 1, nc)
+    n = mesh.nodes
+    dt = 1e-3 * (2.0 / nc) / 0.05
+    prob = solvers.SolidBodyDrift(mesh, Nt, dt, order=order)
+    x, y = mesh.coordinates()
+    rng = np.random.default_rng(11)
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1)
+    outs = []
+    for strips, tiles in ((False, False), (True, False), (True, True)):
+        prob.ctx.set_fusion(strips, tiles)
+        uk = np.zeros((Nt + 1) * n)
+        uk[:n] = u0
+        prob.solve_state(c, uk)
+        log = prob.solver_log(1)
+        assert not np.any(log["flags"] & hp.FLAG_SOLVER_BUDGET)
+        outs.append(uk.copy())
+    assert rel(outs[1], outs[0]) < 1e-11
+    assert rel(outs[2], outs[0]) < 1e-11
+    prob.close()

@@ -15,5 +15,7 @@ d = json.loads(line[-1])
 tag = os.environ.get("TAG", "")
 msg = f"{tag} value={d['value']:.1f} {d['unit']} ms_per_step={d['ms_per_step']:.2f} sweeps={d['config'].get('jacobi_sweeps_max')}"
 if "roofline" in d:
-    msg += " roofline: " + " ".join(f"{k}={v['achieved_GBps']:.0f}GB/s" for k, v in d["roofline"]["kernels"].items())
+    r = d["roofline"]
+    msg += f" | large mesh: {r['fct_steps_per_s']:.1f} steps/s, {r['jacobi_sweeps_per_step']:.0f} sweeps/step; " + " ".join(
+        f"{k}={v['achieved_GBps']:.0f}GB/s({v['avg_launch_ms'] * 1e3:.0f}us x{v['launches']})" for k, v in r["kernels"].items())
 print(msg)
