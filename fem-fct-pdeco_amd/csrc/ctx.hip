@@ -71,6 +71,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_du); dev_free(&ctx->d_y0); dev_free(&ctx->d_y1); dev_free(&ctx->d_y2); dev_free(&ctx->d_rdu);
     dev_free(&ctx->d_rp); dev_free(&ctx->d_rm); dev_free(&ctx->d_part); dev_free(&ctx->d_ctl);
     dev_free(&ctx->d_bigpart); ctx->bigpart_count = 0;
+    dev_free(&ctx->d_partk);
     dev_free(&ctx->d_hA); dev_free(&ctx->d_hN); dev_free(&ctx->d_hrhs); dev_free(&ctx->d_hu);
     dev_free(&ctx->d_hout); dev_free(&ctx->d_hcsr);
     femfct_mesh_release(ctx);
@@ -118,6 +119,7 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     A_(d_rdu, nv); A_(d_rp, nv); A_(d_rm, nv);
     A_(d_part, (size_t)batch * 4 * FEMFCT_MAX_PARTIALS);
     A_(d_ctl, (size_t)batch);
+    A_(d_partk, (size_t)batch * 16 * FEMFCT_MAX_PARTIALS);
     {
         TilePlan tp;
         ctx->bigpart_count = 0;
@@ -132,31 +134,48 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     return FEMFCT_OK;
 }
 
-int femfct_fused_k(const femfct_ctx* ctx) {
+// 0: one sweep per launch; 1: row strips (K sweeps per launch, coarse sweep count);
+// 2: 2-D tiles on a small grid (exact sweep count logged by the last launch)
+static int fusion_mode(const femfct_ctx* ctx, int* K) {
     TilePlan tp;
-    if (femfct_tile_plan(ctx, &tp, false)) return tp.K;
+    if (femfct_tile_plan(ctx, &tp, false)) {
+        *K = tp.K;
+        return femfct_tile_big(ctx, tp) ? 1 : 2;
+    }
     StripPlan pl;
-    if (femfct_strip_plan(ctx, &pl)) return pl.K;
-    return 1;
+    if (femfct_strip_plan(ctx, &pl)) { *K = pl.K; return 1; }
+    *K = 1;
+    return 0;
 }
 
-int femfct_next_budget(const femfct_ctx* ctx, int worst) {
-    const int K = femfct_fused_k(ctx);
+int femfct_fused_k(const femfct_ctx* ctx) {
+    int K;
+    fusion_mode(ctx, &K);
+    return K;
+}
+
+int femfct_next_budget(const femfct_ctx* ctx, int worst, bool coarse) {
+    int K;
+    const int mode = fusion_mode(ctx, &K);
     int b;
-    if (K > 1) b = ((std::max(worst, 1) + K - 1) / K) * K;   // whole launches, no margin
+    if (mode == 2) b = std::max(worst, 1) + (coarse ? 0 : 1);             // exact count + one sweep of margin
+    else if (mode == 1) b = ((std::max(worst, 1) + K - 1) / K) * K;        // whole launches
     else b = std::max(8, worst + worst / 8 + 2);
     return std::min(ctx->max_iters, b);
 }
 
 int femfct_grow_budget(const femfct_ctx* ctx, int budget) {
-    const int K = femfct_fused_k(ctx);
-    if (K > 1) return std::min(ctx->max_iters, budget + K);
+    int K;
+    const int mode = fusion_mode(ctx, &K);
+    if (mode == 2) return std::min(ctx->max_iters, budget + 3);
+    if (mode == 1) return std::min(ctx->max_iters, budget + K);
     return std::min(ctx->max_iters, budget * 2);
 }
 
 int femfct_round_budget(const femfct_ctx* ctx, int b) {
-    b = (b + 3) & ~3;
-    if (b < 4) b = 4;
+    int K;
+    if (fusion_mode(ctx, &K) == 0) b = (b + 3) & ~3;    // fewer distinct graphs for the one-sweep kernels
+    if (b < 1) b = 1;
     if (b > ctx->max_iters) b = ctx->max_iters;
     return b;
 }
@@ -185,6 +204,8 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_STRIPS")) ctx->use_strips = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_STRIP_K")) ctx->strip_k = atoi(e);
     if (const char* e = getenv("FEMFCT_TILES")) ctx->use_tiles = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_EXACT")) ctx->exact_iters = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_STEPS_PER_GRAPH")) ctx->steps_per_graph = std::max(1, atoi(e));
     return femfct_strip_init(ctx);
 }
 

@@ -62,8 +62,10 @@ struct femfct_ctx {
     int sweep_budget = 48;      // adaptive: sweeps enqueued per step (stand-alone femfct_fct_step)
     std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
+    int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    bool exact_iters = false;   // last fused launch logs per-sweep residuals (exact sweep count; measured 10 % slower)
     int32_t bandwidth = 0;      // max |col - row| of the pattern
     int32_t strip_k = 0;        // 0: automatic
     bool implicit_cols = false; // structured mesh in vertex order: neighbour index = row + const offset
@@ -76,6 +78,7 @@ struct femfct_ctx {
     double *d_rp = nullptr, *d_rm = nullptr;                          // R+ / R- [B*n]
     double *d_part = nullptr;                                         // block partials [B*4*MAX_PARTIALS]
     StepCtl* d_ctl = nullptr;                                         // [B]
+    double* d_partk = nullptr;       // [B][16][MAX_PARTIALS] per-sweep residual partials of the last fused launch
     double* d_bigpart = nullptr;     // [B * bigpart_count] residual partials of fused launches on large grids
     int64_t bigpart_count = 0;
     // host staging for the *_host convenience calls
@@ -157,10 +160,10 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
                               const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
                               double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1,
                               int32_t batch);
-struct TilePlan { int tiles, K; };
-bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true);
+struct TilePlan { int tiles, K, H; };
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true, int budget = 0);
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
-                               double* xb, int launch, int g_build, int32_t batch);
+                               double* xb, int launch, int g_build, int32_t batch, bool last);
 bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl);   // more workgroups than in-kernel partials
 int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
@@ -170,7 +173,7 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
 // number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
 int femfct_fused_k(const femfct_ctx* ctx);
 // sweep-budget policy (sweeps to enqueue for the next step sequence)
-int femfct_next_budget(const femfct_ctx* ctx, int worst_iters);
+int femfct_next_budget(const femfct_ctx* ctx, int worst_iters, bool coarse = false);
 int femfct_grow_budget(const femfct_ctx* ctx, int budget);
 
 // kernel classes for profiling

@@ -199,8 +199,25 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int
 
 // Finalise the solve bookkeeping when the sweep budget ran out before `done`.
 __device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, int budget, int iters_per_unit,
-                                               double rel_tol, double* smem) {
+                                               double rel_tol, double* smem, const double* partk, int exact_k) {
     if (ctl->done) return;
+    if (partk && exact_k > 0) {
+        // the last fused launch logged the residual of every sweep's input: exact sweep count
+        const double tolb = rel_tol * ctl->bnorm;
+        int first = -1;
+        double rlast = 0.0;
+        for (int k = 0; k < exact_k; ++k) {
+            rlast = reduce_partials(partk + (int64_t)k * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
+            if (first < 0 && rlast <= tolb) { first = k; break; }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const double bn = ctl->bnorm;
+            ctl->iters = (first >= 0) ? (budget - 1) * iters_per_unit + first + 1 : budget * iters_per_unit;
+            ctl->resid = bn > 0.0 ? rlast / bn : 0.0;
+            if (first < 0) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
+        }
+        return;
+    }
     double rmax = (G < 0) ? ctl->rs[(budget - 1) & 1]
                           : reduce_partials(p + ((budget - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
     // every block computes the same values; block 0 publishes them for later kernels' diagnostics.
@@ -224,7 +241,8 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
                            const double* __restrict__ xa_, const double* __restrict__ xb_,
                            double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
                            double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, int part_count,
-                           int iters_per_unit, double rel_tol, double md_scale, double omega1) {
+                           int iters_per_unit, double rel_tol, double md_scale, double omega1,
+                           const double* __restrict__ partk, int exact_k) {
     __shared__ double smem[32];
     const int W = WT ? WT : Wrt;
     const int bz = blockIdx.y;
@@ -232,7 +250,8 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     // solution buffer: decided by the sweep that detected convergence, else by the budget parity
     const int parity = ctl->done ? ctl->parity : (budget & 1);
-    finalize_solve(ctl, p, part_count ? part_count : (int)gridDim.x, budget, iters_per_unit, rel_tol, smem);
+    finalize_solve(ctl, p, part_count ? part_count : (int)gridDim.x, budget, iters_per_unit, rel_tol, smem,
+                   partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k);
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const double* A = A_ + moff;
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -500,15 +519,17 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     TilePlan tp;
     // Jacobi tiles: small grids reduce the residual partials in the consumer; large grids use the
     // extra reduce kernel (needs the big partial buffer, allocated by femfct_ensure_workspace)
-    const bool tiles = femfct_tile_plan(ctx, &tp, false) && (!femfct_tile_big(ctx, tp) || ctx->d_bigpart);
+    const bool tiles = femfct_tile_plan(ctx, &tp, false, budget) && (!femfct_tile_big(ctx, tp) || ctx->d_bigpart);
     const bool strips = !tiles && femfct_strip_plan(ctx, &pl);
-    int units = budget, part_count = 0, ipu = 1;
+    int units = budget, part_count = 0, ipu = 1, exact_k = 0;
     if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
         ipu = tp.K;
+        exact_k = (femfct_tile_big(ctx, tp) || !ctx->exact_iters) ? 0 : tp.K;
         for (int s = 0; s < units; ++s)
-            femfct_enqueue_tile_jacobi(ctx, tp, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
+            femfct_enqueue_tile_jacobi(ctx, tp, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch,
+                                       exact_k > 0 && s == units - 1);
     } else if (strips) {
         units = (budget + pl.K - 1) / pl.K;
         part_count = pl.S;
@@ -523,7 +544,8 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
     double* ulow = ctx->d_b;
     LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
-             ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0);
+             ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0,
+             exact_k ? ctx->d_partk : nullptr, exact_k);
     femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
     if (tiles) {
         femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch);

@@ -19,7 +19,7 @@
 
 namespace {
 
-struct CheOmegas { double w[8]; };
+struct CheOmegas { double w[10]; };
 
 template <int RPT>
 __global__ void __launch_bounds__(STRIP_T)
@@ -47,7 +47,7 @@ k_strip_jacobi(int n, const int32_t* __restrict__ cols, const double* __restrict
         double rmax = reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, gridDim.x, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
-                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K;
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
                 ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
             }
             return;
@@ -345,10 +345,11 @@ __device__ __forceinline__ TileGeom tile_geom(int N) {
     return g;
 }
 
+template <int H, int EXACT>
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
               double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-              int g_build, double rel_tol, double* __restrict__ bigpart) {
+              int g_build, double rel_tol, double* __restrict__ bigpart, double* __restrict__ partk) {
     constexpr int W = 7;
     __shared__ double xs[2][TILE_L * TILE_LD];
     __shared__ double smem[32];
@@ -372,7 +373,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
                               : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (wg == 0 && threadIdx.x == 0) {
-                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K;
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
                 ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
             }
             return;
@@ -382,7 +383,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     const double* L = L_ + moff;
     const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
     double* xout = ((launch & 1) ? xa_ : xb_) + voff;
-    const TileGeom g = tile_geom<>(N);
+    const TileGeom g = tile_geom<TILE_L - 2 * H, H>(N);
     double lv[W - 1], dg = 1.0, rdg = 1.0, bv = 0.0, xi = 0.0;
 #pragma unroll
     for (int s = 0; s < W - 1; ++s) lv[s] = 0.0;
@@ -398,19 +399,57 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     __syncthreads();
     double rmax = 0.0;
     int cur = 0;
-    for (int k = 0; k < K; ++k) {
-        const double* c = xs[cur];
-        double xn = c[g.self];
-        if (k < g.kvalid) {
-            double acc = bv;
+    if (!EXACT) {
+        for (int k = 0; k < K; ++k) {
+            const double* c = xs[cur];
+            double xn = c[g.self];
+            if (k < g.kvalid) {
+                double acc = bv;
 #pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
-            if (k == K - 1 && g.owned) rmax = fmax(rmax, fabs(acc - dg * xn));
-            xn = acc * rdg;
+                for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+                if (k == K - 1 && g.owned) rmax = fmax(rmax, fabs(acc - dg * xn));
+                xn = acc * rdg;
+            }
+            xs[cur ^ 1][g.self] = xn;
+            __syncthreads();
+            cur ^= 1;
         }
-        xs[cur ^ 1][g.self] = xn;
+    } else {
+        // last launch of the budget, optional: log the residual of every sweep's input so that the
+        // host learns the exact sweep count (fully unrolled: per-sweep values stay in registers)
+        double rk[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            rk[k] = 0.0;
+            if (k < K) {
+                const double* c = xs[cur];
+                double xn = c[g.self];
+                if (k < g.kvalid) {
+                    double acc = bv;
+#pragma unroll
+                    for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+                    if (g.owned) rk[k] = fabs(acc - dg * xn);
+                    if (k == K - 1) rmax = fmax(rmax, rk[k]);
+                    xn = acc * rdg;
+                }
+                xs[cur ^ 1][g.self] = xn;
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        __shared__ double sk[H][STRIP_T / WAVE];
+        const int wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            double v = wave_reduce(rk[k], OpMax());
+            if (lane == 0) sk[k][wid] = v;
+        }
         __syncthreads();
-        cur ^= 1;
+        if (threadIdx.x < H) {
+            double v = 0.0;
+            for (int w = 0; w < STRIP_T / WAVE; ++w) v = fmax(v, sk[threadIdx.x][w]);
+            partk[((int64_t)bz * 16 + threadIdx.x) * FEMFCT_MAX_PARTIALS + wg] = v;
+        }
     }
     if (g.owned) xout[g.i] = xs[cur][g.self];
     rmax = block_reduce(rmax, OpMax(), 0.0, smem);
@@ -433,6 +472,7 @@ k_reduce_resid(const double* __restrict__ bigpart, int64_t count, StepCtl* __res
     if (threadIdx.x == 0) ctl_[bz].rs[launch & 1] = v;
 }
 
+template <int H>
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
             const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
@@ -440,7 +480,7 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
     constexpr int W = 7;
     __shared__ double ys[3][TILE_L * TILE_LD];
     const int64_t voff = (int64_t)blockIdx.z * n;
-    const TileGeom g = tile_geom<>(N);
+    const TileGeom g = tile_geom<TILE_L - 2 * H, H>(N);
     double mv[W - 1], md = 1.0, rmd = 1.0, bv = 0.0, ym = 0.0, yo = 0.0;
 #pragma unroll
     for (int s = 0; s < W - 1; ++s) mv[s] = 0.0;
@@ -483,15 +523,14 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
 // flux + Zalesak limiter + explicit correction in one launch (helpers.py:1818-1870): a 12 x 12
 // tile with a halo of two rings (16 x 16 patch, 256 threads) (R+- of the first ring needs u_L, du/dt of the second);
 // F_ij stays in registers, R+- goes through LDS.
-#define FL_T 12
 #define FL_H 2
-#define FL_L 16
-#define FL_LD 17
+template <int FL_L>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
 __global__ void __launch_bounds__(FL_L * FL_L)
 k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __restrict__ D_,
                   const double* __restrict__ ulow_, const double* __restrict__ du_, const double* __restrict__ ml,
                   double dt, VecRef out_ref, int64_t out_bstride) {
     constexpr int W = 7;
+    constexpr int FL_LD = FL_L + 1, FL_T = FL_L - 2 * FL_H;
     __shared__ double su[FL_L * FL_LD], sd[FL_L * FL_LD], srp[FL_L * FL_LD], srm[FL_L * FL_LD];
     const int bz = blockIdx.z;
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
@@ -512,13 +551,14 @@ k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __re
         for (int s = 1; s < W; ++s) {
             const int64_t idx = (int64_t)s * n + g.i;
             const double uj = su[g.nb[s - 1]];
-            const double fs = M[idx] * (dui - sd[g.nb[s - 1]]) + D_[moff + idx] * (ui - uj);
+            const double mij = M[idx], dij = D_[moff + idx];
+            const double fs = mij * (dui - sd[g.nb[s - 1]]) + dij * (ui - uj);
             f[s - 1] = fs;
             pp += fmax(fs, 0.0);
             pm += fmin(fs, 0.0);
             // a clamped neighbour (outside the grid) has M = D = 0 and must not enter the bounds:
             // its LDS slot then aliases a patch node, so take it only when the coefficient is live
-            const bool live = (M[idx] != 0.0) || (D_[moff + idx] != 0.0);
+            const bool live = (mij != 0.0) || (dij != 0.0);
             umax = live ? fmax(umax, uj) : umax;
             umin = live ? fmin(umin, uj) : umin;
         }
@@ -545,25 +585,47 @@ k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __re
 
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
                                    VecRef out, int64_t out_bstride, int32_t batch) {
-    const int t = (ctx->N + FL_T - 1) / FL_T;
     femfct_prof_begin(ctx, KC_FLUX);
-    hipLaunchKernelGGL(k_tile_flux_limit, dim3(t, t, batch), dim3(FL_L * FL_L), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
-                       ulow, du, ctx->d_ml, dt, out, out_bstride);
+    if (ctx->N <= 512) {
+        const int t = (ctx->N + 11) / 12;
+        hipLaunchKernelGGL(k_tile_flux_limit<16>, dim3(t, t, batch), dim3(256), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
+                           ulow, du, ctx->d_ml, dt, out, out_bstride);
+    } else {
+        const int t = (ctx->N + 27) / 28;
+        hipLaunchKernelGGL(k_tile_flux_limit<32>, dim3(t, t, batch), dim3(1024), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
+                           ulow, du, ctx->d_ml, dt, out, out_bstride);
+    }
     femfct_prof_end(ctx);
     return FEMFCT_OK;
 }
 
-// need_partials: the Jacobi variant publishes one residual partial per workgroup (capped);
-// the Chebyshev variant has no reduction and also serves large meshes, where running 8 iterations
-// per pass over the matrix cuts the HBM traffic per iteration by about half.
-bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials) {
+// The 32 x 32 patch is split as tile + 2 halos with halo H in {8, 9, 10}: H sweeps fit in one launch.
+// Latency regime (small grids): pick the H that needs the fewest launches for the sweep budget
+// (Chebyshev: 19 remaining iterations = 10 + 9 with H = 10).  Bandwidth regime (large grids): H = 8
+// keeps the halo re-reading lowest.  need_partials: the Jacobi variant publishes one residual partial
+// per workgroup, consumed in-kernel up to FEMFCT_MAX_PARTIALS workgroups (else a reduce kernel).
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials, int budget) {
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
-    const int t = (ctx->N + TILE_T - 1) / TILE_T;
+    int H = 8;
+    const bool small = ctx->N <= 512;
+    if (small) {
+        if (budget <= 0) H = 10;
+        else {
+            int best = 1 << 30;
+            for (int h = 8; h <= 10; ++h) {
+                int launches = (budget + h - 1) / h;
+                if (launches < best) { best = launches; H = h; }
+            }
+        }
+    }
+    if (ctx->strip_k >= 8 && ctx->strip_k <= 10) H = ctx->strip_k;   // tuning knob
+    const int T = TILE_L - 2 * H;
+    const int t = (ctx->N + T - 1) / T;
     if (need_partials && (int64_t)t * t > FEMFCT_MAX_PARTIALS) return false;
     if (t > 65535) return false;
     pl->tiles = t;
-    pl->K = TILE_H;
-    if (ctx->strip_k > 0 && ctx->strip_k < TILE_H) pl->K = ctx->strip_k;
+    pl->K = H;
+    pl->H = H;
     return true;
 }
 
@@ -572,12 +634,21 @@ bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl) {
 }
 
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
-                               double* xb, int launch, int g_build, int32_t batch) {
+                               double* xb, int launch, int g_build, int32_t batch, bool last) {
     const bool big = femfct_tile_big(ctx, pl);
+    double* bigp = big ? ctx->d_bigpart : nullptr;
+    double* pk = (last && !big) ? ctx->d_partk : nullptr;
+    dim3 grid(pl.tiles, pl.tiles, batch);
     femfct_prof_begin(ctx, KC_JACOBI);
-    hipLaunchKernelGGL(k_tile_jacobi, dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,
-                       xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol,
-                       big ? ctx->d_bigpart : nullptr);
+#define TJ(HH)                                                                                                          \
+    do {                                                                                                                \
+        if (pk) hipLaunchKernelGGL((k_tile_jacobi<HH, 1>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, \
+                                   xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);         \
+        else hipLaunchKernelGGL((k_tile_jacobi<HH, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa,    \
+                                xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);            \
+    } while (0)
+    if (pl.H == 8) TJ(8); else if (pl.H == 9) TJ(9); else TJ(10);
+#undef TJ
     if (big)
         hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart,
                            (int64_t)pl.tiles * pl.tiles, ctx->d_ctl, launch);
@@ -599,8 +670,10 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
         double* omid = last ? y_out : (which ? bufB0 : bufA0);
         double* oold = last ? nullptr : (which ? bufB1 : bufA1);
         femfct_prof_begin(ctx, KC_CHEB);
-        hipLaunchKernelGGL(k_tile_cheb, dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
-                           ctx->d_M, b, mid, old, omid, oold, k1 - k0, om, md_scale);
+#define TC(HH) hipLaunchKernelGGL((k_tile_cheb<HH>), dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, \
+                                  ctx->N, ctx->d_M, b, mid, old, omid, oold, k1 - k0, om, md_scale)
+        if (pl.H == 8) TC(8); else if (pl.H == 9) TC(9); else TC(10);
+#undef TC
         femfct_prof_end(ctx);
         mid = omid;
         old = oold;

@@ -107,11 +107,11 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
     const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;  // any valid ELL array; multiplied by 0
     int32_t* lv = ctx->d_level;
     auto begin = [&]() { return FEMFCT_OK; };
-    auto step = [&](int budget, int) {
+    auto step = [&](int budget, int, int reps) {
         femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
                                  key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
             femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
                                          rot_scale, bx, by, ctx->d_trA, batch);
@@ -146,12 +146,12 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
         }
         return FEMFCT_OK;
     };
-    auto step = [&](int budget, int) {
+    auto step = [&](int budget, int, int reps) {
         femfct_ctx::GraphKey key{(uint64_t)3, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(uhat), key_bits(p_traj), key_bits(num_steps), key_bits(dt), key_bits(eps),
                                  key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
                                  key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // level counter = n: control c_n (finaltime.py:213), p_{n+1} -> p_n
             femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
                                          rot_scale, bx, by, ctx->d_trA, batch);

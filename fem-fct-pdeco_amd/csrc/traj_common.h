@@ -6,6 +6,8 @@
 #include "forms.h"
 
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
 
 int femfct_ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps);
 int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch);
@@ -23,7 +25,20 @@ static inline int femfct_round_kry_budget(const femfct_ctx* ctx, int b) {
     return b;
 }
 
-// Replays `step(jacobi_budget, krylov_budget)` num_steps times, then inspects the per-step solver
+// Captured graph holding `reps` consecutive, identical time steps (the time level is a device counter).
+template <class F>
+int femfct_run_graph_reps(femfct_ctx* ctx, femfct_ctx::GraphKey key, int reps, F&& enqueue_one) {
+    key.push_back(key_bits((int32_t)reps));
+    return femfct_run_graph(ctx, key, [&]() {
+        for (int r = 0; r < reps; ++r) {
+            int rc = enqueue_one();
+            if (rc != FEMFCT_OK) return rc;
+        }
+        return (int)FEMFCT_OK;
+    });
+}
+
+// Replays `step(jacobi_budget, krylov_budget, reps)` until num_steps are done, then inspects the per-step solver
 // logs; if a sweep/iteration budget was too small anywhere the whole sweep is repeated with a
 // larger one (the sweep's inputs are never overwritten, so a repeat is exact).
 template <class Begin, class Step>
@@ -40,8 +55,10 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         if (rc != FEMFCT_OK) return rc;
         int32_t init[2] = {level0, 0};
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_level, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-        for (int32_t k = 0; k < num_steps; ++k) {
-            rc = step(budget, kbudget);
+        // several identical time steps per captured graph: fewer graph launches, no inter-graph gaps
+        const int32_t per_graph = std::max(1, std::min(ctx->steps_per_graph, num_steps));
+        for (int32_t k = 0; k < num_steps; k += per_graph) {
+            rc = step(budget, kbudget, std::min(per_graph, num_steps - k));
             if (rc != FEMFCT_OK) return rc;
         }
         ctx->h_log.resize((size_t)num_steps * batch);
@@ -58,9 +75,10 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         ctx->log_steps = num_steps;
         ctx->log_batch = batch;
         int worst = 0, kworst = 0;
-        bool short_budget = false, kshort = false;
+        bool short_budget = false, kshort = false, coarse = false;
         double worst_res = 0.0, kworst_res = 0.0;
         for (const StepCtl& c : ctx->h_log) {
+            if (c.iters > worst) coarse = (c.flags & FEMFCT_FLAG_COARSE_ITERS) != 0;
             worst = std::max(worst, c.iters);
             if (c.flags & FEMFCT_FLAG_SOLVER_BUDGET) { short_budget = true; worst_res = std::max(worst_res, c.resid); }
         }
@@ -74,8 +92,11 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
                 }
             }
         }
+        if (getenv("FEMFCT_DEBUG"))
+            fprintf(stderr, "[femfct] sweep kind %d: budget %d (krylov %d) worst %d kworst %d short %d/%d\n", kind, budget,
+                    kbudget, worst, kworst, (int)short_budget, (int)kshort);
         if (!short_budget && !kshort) {
-            ctx->kind_budget[kind] = femfct_next_budget(ctx, worst);
+            ctx->kind_budget[kind] = femfct_next_budget(ctx, worst, coarse);
             if (krylov) ctx->kind_kbudget[kind] = std::min(ctx->kry_max_iters, std::max(8, kworst + kworst / 4 + 2));
             return FEMFCT_OK;
         }

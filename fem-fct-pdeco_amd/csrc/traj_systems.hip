@@ -136,10 +136,10 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
         ls.s1 = 1.0; ls.k1 = 1.0; ls.p1 = make_ref(c_level); ls.p1_bs = n;
         return femfct_enqueue_load(ctx, ls, ctx->d_trRhs, batch);
     };
-    auto step = [&](int budget, int) {
+    auto step = [&](int budget, int, int reps) {
         auto key = KEY((uint64_t)10, key_bits(Aw_ell), key_bits(c_level), key_bits(u_traj), key_bits(num_steps),
                        key_bits(dt), key_bits(eps), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol));
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             WMassSpec ws;  // Mat_rhs = -M + M_u2/3 (helpers.py:953-955)
             ws.alpha = -1.0; ws.beta = 1.0 / 3.0; ws.f1 = L(u_traj, 0); ws.f2 = L(u_traj, 0); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trN, batch);
@@ -165,11 +165,11 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
         for (int32_t b = 0; b < batch; ++b) femfct_enqueue_axpby(ctx, wn, eps, ctx->d_Ad, 1.0, Aw_ell, ctx->d_trA + b * wn);
         return terminal_diff(ctx, uhat_T, u_traj, p_traj, num_steps, batch);
     };
-    auto step = [&](int budget, int) {
+    auto step = [&](int budget, int, int reps) {
         auto key = KEY((uint64_t)11, key_bits(Aw_ell), key_bits(u_traj), key_bits(uhat_T), key_bits(p_traj),
                        key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(batch), key_bits((int32_t)budget),
                        key_bits(ctx->rel_tol));
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             WMassSpec ws;  // Mat_rhs = M_u2(u_n) - M (helpers.py:1032-1034)
             ws.alpha = -1.0; ws.beta = 1.0; ws.f1 = L(u_traj, 0); ws.f2 = L(u_traj, 0); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trN, batch);
@@ -205,12 +205,12 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
         ws.alpha = 1.0; ws.gamma = dt; ws.base = ctx->d_trBase2;
         return femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
     };
-    auto step = [&](int budget, int kbudget) {
+    auto step = [&](int budget, int kbudget, int reps) {
         auto key = KEY((uint64_t)12, key_bits(Aw_ell), key_bits(c_level), key_bits(u_traj), key_bits(v_traj),
                        key_bits(num_steps), key_bits(dt), key_bits(Du), key_bits(Dv), key_bits(c_b), key_bits(gam),
                        key_bits(om1), key_bits(om2), key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget),
                        key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol));
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             LoadSpec l1;  // (gamma/r*c + gamma*u_n^2*v_n)*v*dx  (helpers.py:584-585)
             l1.s1 = 1.0; l1.k1 = gam / rescaling; l1.p1 = make_ref(c_level); l1.p1_bs = n;
             l1.k2 = gam; l1.q1 = L(u_traj, 0); l1.q2 = L(u_traj, 0); l1.q3 = L(v_traj, 0);
@@ -255,12 +255,12 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
         terminal_diff(ctx, uhat_T, u_traj, p_traj, num_steps, batch);
         return terminal_diff(ctx, vhat_T, v_traj, q_traj, num_steps, batch);
     };
-    auto step = [&](int budget, int kbudget) {
+    auto step = [&](int budget, int kbudget, int reps) {
         auto key = KEY((uint64_t)13, key_bits(AwT_ell), key_bits(u_traj), key_bits(v_traj), key_bits(uhat_T),
                        key_bits(vhat_T), key_bits(p_traj), key_bits(q_traj), key_bits(num_steps), key_bits(dt),
                        key_bits(Du), key_bits(Dv), key_bits(gam), key_bits(om1), key_bits(om2), key_bits(batch),
                        key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol));
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // q first (helpers.py:683-686): Mat_q = M + dt*(Dv*Ad - omega2*A' + gamma*M_u2(u_n))
             WMassSpec wq;
             wq.gamma = 1.0; wq.base = ctx->d_trBase; wq.beta = dt * gam;
@@ -306,12 +306,12 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
         ws.alpha = 1.0 + dt * delta; ws.gamma = dt * Df; ws.base = ctx->d_Ad;
         return femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
     };
-    auto step = [&](int budget, int kbudget) {
+    auto step = [&](int budget, int kbudget, int reps) {
         auto key = KEY((uint64_t)14, key_bits(c_level), key_bits(u_traj), key_bits(v_traj), key_bits(num_steps),
                        key_bits(dt), key_bits(delta), key_bits(Dm), key_bits(Df), key_bits(chi), key_bits(eta),
                        key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget), key_bits((int32_t)kbudget),
                        key_bits(ctx->rel_tol), key_bits(ctx->kry_tol));
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             LoadSpec l2;  // assemble(v_n*v*dx + dt*c*u_n/r*v*dx)  (helpers.py:1339-1340)
             l2.s0 = 1.0; l2.mx = L(v_traj, 0); l2.mx_bs = ts; l2.s1 = dt / rescaling; l2.k2 = 1.0;
             l2.q1 = make_ref(c_level); l2.q1_bs = n; l2.q2 = L(u_traj, 0); l2.q2_bs = ts;
@@ -353,13 +353,13 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
         }
         return FEMFCT_OK;
     };
-    auto step = [&](int budget, int kbudget) {
+    auto step = [&](int budget, int kbudget, int reps) {
         auto key = KEY((uint64_t)15, key_bits(u_traj), key_bits(v_traj), key_bits(uhat), key_bits(vhat), key_bits(p_traj),
                        key_bits(q_traj), key_bits(c_traj), key_bits(num_steps), key_bits(dt), key_bits(delta),
                        key_bits(Dm), key_bits(Df), key_bits(chi), key_bits(eta), key_bits(rescaling), key_bits(alltime),
                        key_bits(batch), key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol),
                        key_bits(ctx->kry_tol));
-        return femfct_run_graph(ctx, key, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // Mat_p = Dm*Ad - chi*Aa'(u_n, v_n)  (helpers.py:1499-1503)
             femfct_enqueue_chtxs_matrix(ctx, 1, L(u_traj, 0), ts, L(v_traj, 0), ts, Dm, chi, eta, ctx->d_trA, batch);
             LoadSpec lp;  // assemble(c_n*q_{n+1}/r*w*dx) [+ uhat_n - u_n]  (helpers.py:1505-1507)

@@ -54,6 +54,7 @@ typedef struct femfct_ctx femfct_ctx;
 #define FEMFCT_FLAG_MMATRIX_ROWSUM 1  /* some row sum of the low-order matrix <= 0:
                                          the "3: False" diagnostic of helpers.py:1796-1799 */
 #define FEMFCT_FLAG_SOLVER_BUDGET  2  /* sweep/iteration budget exhausted before tolerance */
+#define FEMFCT_FLAG_COARSE_ITERS   4  /* solver_iters is an upper bound (whole fused launches), not the exact count */
 
 /* DoF numbering of the structured mesh */
 #define FEMFCT_ORDER_VERTEX 0         /* iy*N+ix (dolfin vertex order) */
