@@ -345,7 +345,9 @@ __device__ __forceinline__ TileGeom tile_geom(int N) {
     return g;
 }
 
-template <int H, int EXACT>
+// BIG = 1: grids with more workgroups than in-kernel partials (bandwidth regime); the residual maxima
+// go through k_reduce_resid.  A template parameter so that profiles list the two regimes separately.
+template <int H, int EXACT, int BIG>
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
               double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
@@ -369,8 +371,8 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
         }
     } else {
         bnorm = ctl->bnorm;
-        double rmax = bigpart ? ctl->rs[(launch - 1) & 1]
-                              : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        double rmax = BIG ? ctl->rs[(launch - 1) & 1]
+                          : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (wg == 0 && threadIdx.x == 0) {
                 ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
@@ -454,7 +456,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     if (g.owned) xout[g.i] = xs[cur][g.self];
     rmax = block_reduce(rmax, OpMax(), 0.0, smem);
     if (threadIdx.x == 0) {
-        if (bigpart) bigpart[(int64_t)bz * nwg + wg] = rmax;
+        if (BIG) bigpart[(int64_t)bz * nwg + wg] = rmax;
         else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
     }
 }
@@ -618,7 +620,7 @@ bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials, i
             }
         }
     }
-    if (ctx->strip_k >= 8 && ctx->strip_k <= 10) H = ctx->strip_k;   // tuning knob
+    if (small && ctx->strip_k >= 8 && ctx->strip_k <= 10) H = ctx->strip_k;   // tuning knob (latency regime only)
     const int T = TILE_L - 2 * H;
     const int t = (ctx->N + T - 1) / T;
     if (need_partials && (int64_t)t * t > FEMFCT_MAX_PARTIALS) return false;
@@ -642,9 +644,11 @@ int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double
     femfct_prof_begin(ctx, KC_JACOBI);
 #define TJ(HH)                                                                                                          \
     do {                                                                                                                \
-        if (pk) hipLaunchKernelGGL((k_tile_jacobi<HH, 1>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, \
-                                   xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);         \
-        else hipLaunchKernelGGL((k_tile_jacobi<HH, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa,    \
+        if (big) hipLaunchKernelGGL((k_tile_jacobi<8, 0, 1>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,  \
+                                    xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);    \
+        else if (pk) hipLaunchKernelGGL((k_tile_jacobi<HH, 1, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, \
+                                        b, xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk); \
+        else hipLaunchKernelGGL((k_tile_jacobi<HH, 0, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, \
                                 xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);            \
     } while (0)
     if (pl.H == 8) TJ(8); else if (pl.H == 9) TJ(9); else TJ(10);
