@@ -77,6 +77,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     femfct_mesh_release(ctx);
     ctx->h_indptr.clear(); ctx->h_indices.clear(); ctx->h_csr2ell.clear(); ctx->h_cols.clear();
     dev_free(&ctx->d_trA); dev_free(&ctx->d_trN); dev_free(&ctx->d_trRhs); dev_free(&ctx->d_level); dev_free(&ctx->d_log);
+    dev_free(&ctx->d_ticket);
     ctx->tr_batch = 0; ctx->tr_steps = 0;
     dev_free(&ctx->d_scratch); ctx->scratch_count = 0;
     dev_free(&ctx->d_kry); dev_free(&ctx->d_kry_part);
@@ -205,6 +206,8 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_STRIP_K")) ctx->strip_k = atoi(e);
     if (const char* e = getenv("FEMFCT_TILES")) ctx->use_tiles = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_EXACT")) ctx->exact_iters = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_STEPS_PER_GRAPH")) ctx->steps_per_graph = std::max(1, atoi(e));
     return femfct_strip_init(ctx);
 }

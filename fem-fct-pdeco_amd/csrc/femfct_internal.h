@@ -65,6 +65,8 @@ struct femfct_ctx {
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    bool fuse_end = true;       // log + level advance done by the last workgroup of the step's final kernel
+    bool fuse_dudt = true;      // du/dt rhs + first Chebyshev iterations in one tile launch (small grids)
     bool exact_iters = false;   // last fused launch logs per-sweep residuals (exact sweep count; measured 10 % slower)
     int32_t bandwidth = 0;      // max |col - row| of the pattern
     int32_t strip_k = 0;        // 0: automatic
@@ -94,6 +96,9 @@ struct femfct_ctx {
     double *d_trA = nullptr, *d_trN = nullptr, *d_trRhs = nullptr;  // per-step operators [B*W*n], [B*n]
     int32_t* d_level = nullptr;                                     // [2]: current level, step ordinal
     StepCtl* d_log = nullptr;                                       // [tr_steps * tr_batch]
+    unsigned* d_ticket = nullptr;                                   // last-block ticket of the fused step end
+    int end_req_delta = 0;          // != 0: the next step's last kernel also logs + advances the level
+    bool end_req_krylov = false, end_fused = false;
     std::vector<StepCtl> h_log;                                     // last trajectory's log
     int32_t log_steps = 0, log_batch = 0;
 
@@ -169,7 +174,10 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
                              double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch);
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
-                                   struct VecRef out, int64_t out_bstride, int32_t batch);
+                                   struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end);
+int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
+                                  int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
+                                  const double* omegas, double md_scale, int32_t batch);
 // number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
 int femfct_fused_k(const femfct_ctx* ctx);
 // sweep-budget policy (sweeps to enqueue for the next step sequence)

@@ -20,6 +20,7 @@
 //   k_limit       alpha_ij, Fbar, u^{n+1}                           W*12+40  B
 #include "femfct_internal.h"
 #include "device_utils.h"
+#include "solve_ctl.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -197,40 +198,6 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int
     if (threadIdx.x == 0) p[(sweep & 1) * FEMFCT_MAX_PARTIALS + blockIdx.x] = rmax;
 }
 
-// Finalise the solve bookkeeping when the sweep budget ran out before `done`.
-__device__ __forceinline__ void finalize_solve(StepCtl* ctl, double* p, int G, int budget, int iters_per_unit,
-                                               double rel_tol, double* smem, const double* partk, int exact_k) {
-    if (ctl->done) return;
-    if (partk && exact_k > 0) {
-        // the last fused launch logged the residual of every sweep's input: exact sweep count
-        const double tolb = rel_tol * ctl->bnorm;
-        int first = -1;
-        double rlast = 0.0;
-        for (int k = 0; k < exact_k; ++k) {
-            rlast = reduce_partials(partk + (int64_t)k * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
-            if (first < 0 && rlast <= tolb) { first = k; break; }
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            const double bn = ctl->bnorm;
-            ctl->iters = (first >= 0) ? (budget - 1) * iters_per_unit + first + 1 : budget * iters_per_unit;
-            ctl->resid = bn > 0.0 ? rlast / bn : 0.0;
-            if (first < 0) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
-        }
-        return;
-    }
-    double rmax = (G < 0) ? ctl->rs[(budget - 1) & 1]
-                          : reduce_partials(p + ((budget - 1) & 1) * FEMFCT_MAX_PARTIALS, G, OpMax(), 0.0, smem);
-    // every block computes the same values; block 0 publishes them for later kernels' diagnostics.
-    // parity is derived locally below (ctl->parity is only written here by block 0 and read by
-    // later kernels, never by other blocks of this kernel).
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double bn = ctl->bnorm;
-        ctl->iters = budget * iters_per_unit;
-        ctl->resid = bn > 0.0 ? rmax / bn : 0.0;
-        if (!(rmax <= rel_tol * bn)) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // k_dudt_rhs: r = rhs - A u_L (helpers.py:1814) fused with Chebyshev iterate 1
 // (y_1 = omega_1 * r / (1.25 diag M), helpers.py:175-182 with y_0 = y_-1 = 0).
@@ -251,7 +218,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
     // solution buffer: decided by the sweep that detected convergence, else by the budget parity
     const int parity = ctl->done ? ctl->parity : (budget & 1);
     finalize_solve(ctl, p, part_count ? part_count : (int)gridDim.x, budget, iters_per_unit, rel_tol, smem,
-                   partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k);
+                   partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, blockIdx.x == 0);
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const double* A = A_ + moff;
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -543,12 +510,21 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     }
     // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
     double* ulow = ctx->d_b;
-    LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
-             ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0,
-             exact_k ? ctx->d_partk : nullptr, exact_k);
-    femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
+    if (tiles && !femfct_tile_big(ctx, tp) && ctx->fuse_dudt) {
+        std::vector<double> om;
+        cheb_omegas(20, 0.5, 2.0, om);
+        femfct_enqueue_tile_dudt_cheb(ctx, A, rhs, rhs_bstride, ulow, units, part_count, ipu, exact_k, 20, om.data(), 1.25,
+                                      batch);
+    } else {
+        LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
+                 ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0,
+                 exact_k ? ctx->d_partk : nullptr, exact_k);
+        femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
+    }
     if (tiles) {
-        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch);
+        const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
+        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch, fuse_end);
+        if (fuse_end) ctx->end_fused = true;
     } else {
         LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt,
                  ctx->d_F, ctx->d_rp, ctx->d_rm);

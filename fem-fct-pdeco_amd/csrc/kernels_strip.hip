@@ -12,6 +12,8 @@
 // Works for any ELL pattern whose bandwidth admits K >= 2 within the LDS/register budget.
 #include "femfct_internal.h"
 #include "device_utils.h"
+#include "solve_ctl.h"
+#include "forms.h"
 
 #include <math.h>
 
@@ -525,12 +527,25 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
 // flux + Zalesak limiter + explicit correction in one launch (helpers.py:1818-1870): a 12 x 12
 // tile with a halo of two rings (16 x 16 patch, 256 threads) (R+- of the first ring needs u_L, du/dt of the second);
 // F_ij stays in registers, R+- goes through LDS.
+// optional tail of the step, done by the last workgroup to finish (ticket): copy the solver control
+// blocks to the per-step log and move the time-level counter -- saves the separate k_step_end launch
+struct EndArgs {
+    int32_t* level;          // null: nothing to do
+    int delta;
+    const StepCtl* ctl;
+    StepCtl* log;
+    const KrylovCtl* kctl;   // may be null
+    KrylovCtl* klog;
+    int batch;
+    unsigned* ticket;
+};
+
 #define FL_H 2
 template <int FL_L>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
 __global__ void __launch_bounds__(FL_L * FL_L)
 k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __restrict__ D_,
                   const double* __restrict__ ulow_, const double* __restrict__ du_, const double* __restrict__ ml,
-                  double dt, VecRef out_ref, int64_t out_bstride) {
+                  double dt, VecRef out_ref, int64_t out_bstride, EndArgs e) {
     constexpr int W = 7;
     constexpr int FL_LD = FL_L + 1, FL_T = FL_L - 2 * FL_H;
     __shared__ double su[FL_L * FL_LD], sd[FL_L * FL_LD], srp[FL_L * FL_LD], srm[FL_L * FL_LD];
@@ -581,21 +596,52 @@ k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __re
         double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
         out[g.i] = ui + dt * fbar / mli;
     }
+    if (e.level) {
+        // every workgroup has resolved its level-dependent addresses before it draws a ticket, so the
+        // workgroup that draws the last one may move the level
+        __shared__ int is_last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+            is_last = (atomicAdd(e.ticket, 1u) == total - 1);
+        }
+        __syncthreads();
+        if (is_last) {
+            const int ord = e.level[1];
+            for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
+                e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
+                if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                e.level[0] += e.delta;
+                e.level[1] = ord + 1;
+                *e.ticket = 0u;
+            }
+        }
+    }
 }
 
 }  // namespace
 
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
-                                   VecRef out, int64_t out_bstride, int32_t batch) {
+                                   VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end) {
+    EndArgs e;
+    e.level = nullptr;
+    if (fuse_end) {
+        e.level = ctx->d_level; e.delta = ctx->end_req_delta; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
+        e.kctl = ctx->end_req_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr; e.klog = (KrylovCtl*)ctx->d_klog;
+        e.batch = batch; e.ticket = ctx->d_ticket;
+    }
     femfct_prof_begin(ctx, KC_FLUX);
     if (ctx->N <= 512) {
         const int t = (ctx->N + 11) / 12;
         hipLaunchKernelGGL(k_tile_flux_limit<16>, dim3(t, t, batch), dim3(256), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
-                           ulow, du, ctx->d_ml, dt, out, out_bstride);
+                           ulow, du, ctx->d_ml, dt, out, out_bstride, e);
     } else {
         const int t = (ctx->N + 27) / 28;
         hipLaunchKernelGGL(k_tile_flux_limit<32>, dim3(t, t, batch), dim3(1024), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
-                           ulow, du, ctx->d_ml, dt, out, out_bstride);
+                           ulow, du, ctx->d_ml, dt, out, out_bstride, e);
     }
     femfct_prof_end(ctx);
     return FEMFCT_OK;
@@ -684,4 +730,117 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
         which ^= 1;
     }
     return FEMFCT_OK;
+}
+
+// ===========================================================================================
+// du/dt right-hand side + the first Chebyshev iterations in one launch (latency regime):
+//   r = rhs - A u_L (helpers.py:1814), y_1 = w_1 r / Md, then iterations 2..K+1 (helpers.py:175-184).
+// 12 x 12 tile + halo 10: one ring is spent on A u_L, nine on Chebyshev iterations 2..10.
+// Also finalises the low-order solve's bookkeeping (what k_dudt_rhs does in the unfused sequence).
+// ===========================================================================================
+namespace {
+
+__global__ void __launch_bounds__(STRIP_T)
+k_tile_dudt_cheb(int n, int N, const double* __restrict__ A_, VecRef rhs_ref, int64_t rhs_bstride,
+                 const double* __restrict__ M, const double* __restrict__ xa_, const double* __restrict__ xb_,
+                 double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ omid_,
+                 double* __restrict__ oold_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget,
+                 int part_count, int iters_per_unit, double rel_tol, const double* __restrict__ partk, int exact_k,
+                 int K, CheOmegas om, double md_scale, double omega1) {
+    constexpr int W = 7, H = 10;
+    __shared__ double ys[3][TILE_L * TILE_LD];
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    StepCtl* ctl = ctl_ + bz;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int parity = ctl->done ? ctl->parity : (budget & 1);
+    finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
+                   partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* x = (parity ? xb_ : xa_) + voff;
+    const double* rhs = vec_ptr(rhs_ref);
+    if (rhs) rhs += bz * rhs_bstride;
+    const TileGeom g = tile_geom<TILE_L - 2 * H, H>(N);
+    double av[W], mv[W - 1], md = 1.0, rmd = 1.0, ui = 0.0, ri = 0.0;
+#pragma unroll
+    for (int s = 0; s < W; ++s) av[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) mv[s] = 0.0;
+    if (g.inside) {
+        md = M[g.i];
+        rmd = 1.0 / (md_scale * md);
+#pragma unroll
+        for (int s = 0; s < W; ++s) av[s] = A_[moff + (int64_t)s * n + g.i];
+#pragma unroll
+        for (int s = 1; s < W; ++s) mv[s - 1] = M[(int64_t)s * n + g.i];
+        ui = x[g.i];
+        ri = rhs ? rhs[g.i] : 0.0;
+    }
+    ys[2][g.self] = ui;
+    __syncthreads();
+    // r = rhs - A u_L on every node whose neighbours are in the patch
+    double r = 0.0, y1 = 0.0;
+    if (g.kvalid >= 1) {
+        double acc = av[0] * ui;
+#pragma unroll
+        for (int s = 1; s < W; ++s) acc += av[s] * ys[2][g.nb[s - 1]];
+        r = -acc + ri;
+        y1 = omega1 * (r / (md_scale * md));
+    }
+    __syncthreads();
+    ys[0][g.self] = 0.0;
+    ys[1][g.self] = y1;
+    __syncthreads();
+    int io = 0, im = 1, in_ = 2;
+    for (int k = 0; k < K; ++k) {
+        const double* ymd = ys[im];
+        const double ymv = ymd[g.self];
+        double yn = ymv;
+        if (k + 1 < g.kvalid) {      // one ring already spent on A u_L
+            double acc = md * ymv;
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
+            const double z = (r - acc) * rmd;
+            const double yov = ys[io][g.self];
+            yn = om.w[k] * (z + ymv - yov) + yov;
+        }
+        ys[in_][g.self] = yn;
+        __syncthreads();
+        int t = io; io = im; im = in_; in_ = t;
+    }
+    if (g.owned) {
+        ulow_[voff + g.i] = ui;
+        rdu_[voff + g.i] = r;
+        omid_[voff + g.i] = ys[im][g.self];
+        if (oold_) oold_[voff + g.i] = ys[io][g.self];
+    }
+}
+
+}  // namespace
+
+// r, y_1 and Chebyshev iterations 2..(K+1) in one launch, the rest in ceil(.../10) tile launches.
+int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, VecRef rhs, int64_t rhs_bstride, double* ulow,
+                                  int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
+                                  const double* omegas, double md_scale, int32_t batch) {
+    constexpr int H = 10;
+    const int T = TILE_L - 2 * H, t = (ctx->N + T - 1) / T;
+    const int K = std::min(iters - 1, H - 1);            // iterations 2..K+1 here
+    CheOmegas om;
+    for (int k = 0; k < K; ++k) om.w[k] = omegas[k + 1];
+    const bool last = (K + 1 == iters);
+    double* omid = last ? ctx->d_du : ctx->d_y0;
+    double* oold = last ? nullptr : ctx->d_y2;
+    femfct_prof_begin(ctx, KC_DUDT_RHS);
+    hipLaunchKernelGGL(k_tile_dudt_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, A, rhs,
+                       rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow, ctx->d_rdu, omid, oold, ctx->d_part, ctx->d_ctl,
+                       budget_units, part_count, iters_per_unit, ctx->rel_tol, exact_k ? ctx->d_partk : nullptr, exact_k,
+                       K, om, md_scale, omegas[0]);
+    femfct_prof_end(ctx);
+    if (last) return FEMFCT_OK;
+    TilePlan tp;
+    tp.H = H; tp.K = H; tp.tiles = t;
+    // remaining iterations K+2 .. iters; inputs (mid, old) = (y0, y2); scratch pair (y1, rp) then (y0, y2)
+    return femfct_enqueue_tile_cheb(ctx, tp, ctx->d_rdu, ctx->d_y0, ctx->d_y2, ctx->d_du, K + 2, iters, omegas, md_scale,
+                                    ctx->d_y1, ctx->d_rp, ctx->d_y0, ctx->d_y2, batch);
 }

@@ -46,7 +46,19 @@ __global__ void k_step_end(int32_t* level, int delta, const StepCtl* __restrict_
 
 }  // namespace
 
+// The FCT step is the last operation of this kind of time step: let its final kernel log and advance.
+void femfct_request_fused_end(femfct_ctx* ctx, int delta, bool with_krylov) {
+    ctx->end_req_delta = ctx->fuse_end ? delta : 0;
+    ctx->end_req_krylov = with_krylov;
+    ctx->end_fused = false;
+}
+
 int femfct_enqueue_step_end(femfct_ctx* ctx, int delta, int32_t batch, bool with_krylov) {
+    ctx->end_req_delta = 0;
+    if (ctx->end_fused) {   // already done by the step's last kernel
+        ctx->end_fused = false;
+        return FEMFCT_OK;
+    }
     hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, ctx->d_level, delta, ctx->d_ctl, ctx->d_log,
                        with_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr, (KrylovCtl*)ctx->d_klog, batch);
     return FEMFCT_OK;
@@ -80,6 +92,10 @@ int femfct_ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps) {
         ctx->tr_batch = batch;
     }
     if (!ctx->d_level) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_level, sizeof(int32_t) * 2));
+    if (!ctx->d_ticket) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ticket, sizeof(unsigned)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(unsigned), ctx->stream));
+    }
     if (steps > ctx->tr_steps || !ctx->d_log) {
         femfct_drop_graphs(ctx);
         if (ctx->d_log) hipFree(ctx->d_log);
@@ -115,6 +131,7 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
             femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
                                          rot_scale, bx, by, ctx->d_trA, batch);
+            femfct_request_fused_end(ctx, 1, false);
             int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, make_ref(nullptr), 0,
                                             make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
                                             tstride, batch, budget);
@@ -161,6 +178,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
                                          ctx->d_trRhs, batch);
                 rhs = make_ref(ctx->d_trRhs);
             }
+            femfct_request_fused_end(ctx, -1, false);
             int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
                                             dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
             if (r != FEMFCT_OK) return r;

@@ -12,6 +12,7 @@
 int femfct_ensure_traj_ws(femfct_ctx* ctx, int32_t batch, int32_t steps);
 int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch);
 int femfct_enqueue_step_end(femfct_ctx* ctx, int delta, int32_t batch, bool with_krylov);
+void femfct_request_fused_end(femfct_ctx* ctx, int delta, bool with_krylov);
 int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, VecRef rhs,
                             int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
                             int64_t out_bstride, int32_t batch, int32_t budget);

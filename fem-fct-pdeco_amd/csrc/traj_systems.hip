@@ -143,6 +143,7 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
             WMassSpec ws;  // Mat_rhs = -M + M_u2/3 (helpers.py:953-955)
             ws.alpha = -1.0; ws.beta = 1.0 / 3.0; ws.f1 = L(u_traj, 0); ws.f2 = L(u_traj, 0); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trN, batch);
+            femfct_request_fused_end(ctx, 1, false);
             int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, ctx->d_trN, 0, make_ref(ctx->d_trRhs), n, L(u_traj, 0), ts,
                                             dt, L(u_traj, 1), ts, batch, budget);
             if (r != FEMFCT_OK) return r;
@@ -173,6 +174,7 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
             WMassSpec ws;  // Mat_rhs = M_u2(u_n) - M (helpers.py:1032-1034)
             ws.alpha = -1.0; ws.beta = 1.0; ws.f1 = L(u_traj, 0); ws.f2 = L(u_traj, 0); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trN, batch);
+            femfct_request_fused_end(ctx, -1, false);
             int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, ctx->d_trN, 0, make_ref(nullptr), 0, L(p_traj, 1), ts, dt,
                                             L(p_traj, 0), ts, batch, budget);
             if (r != FEMFCT_OK) return r;
@@ -280,6 +282,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
             lp.s1 = 1.0; lp.k2 = -2.0 * gam; lp.q1 = L(u_traj, 0); lp.q2 = L(v_traj, 0); lp.q3 = L(q_traj, 0);
             lp.q1_bs = lp.q2_bs = lp.q3_bs = ts;
             femfct_enqueue_load(ctx, lp, ctx->d_trRhs, batch);
+            femfct_request_fused_end(ctx, -1, true);
             r = femfct_enqueue_step_ref(ctx, ctx->d_trA, ctx->d_trN, 0, make_ref(ctx->d_trRhs), n, L(p_traj, 1), ts, dt,
                                         L(p_traj, 0), ts, batch, budget);
             if (r != FEMFCT_OK) return r;
@@ -320,6 +323,7 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
             if (r != FEMFCT_OK) return r;
             // A_var1 = Dm*Ad - chi*Aa(u_n, v_{n+1})  (helpers.py:1350-1352)
             femfct_enqueue_chtxs_matrix(ctx, 0, L(u_traj, 0), ts, L(v_traj, 1), ts, Dm, chi, eta, ctx->d_trA, batch);
+            femfct_request_fused_end(ctx, 1, true);
             r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, make_ref(nullptr), 0, L(u_traj, 0), ts, dt,
                                         L(u_traj, 1), ts, batch, budget);
             if (r != FEMFCT_OK) return r;
