@@ -1,0 +1,138 @@
+"""Edge cases of the step operator through the C ABI (-m gpu): generic (non-mesh) sparsity patterns
+with a different ELL width, tiny meshes, zero data, solver failure reporting."""
+import importlib
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix, diags, lil_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    mod = importlib.import_module("fem-fct-pdeco_amd")
+    mod.fct_helpers.VERBOSE = False
+    return mod
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def nine_point_problem(N, rng):
+    """A 'mass' matrix and a flux matrix on the 9-point stencil graph of an N x N grid (ELL width 9,
+    not a P1 mesh): exercises the runtime-width kernels and the strip-fused path on a generic pattern."""
+    n = N * N
+    M = lil_matrix((n, n))
+    A = lil_matrix((n, n))
+    for iy in range(N):
+        for ix in range(N):
+            i = iy * N + ix
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    jx, jy = ix + dx, iy + dy
+                    if 0 <= jx < N and 0 <= jy < N:
+                        j = jy * N + jx
+                        M[i, j] = 4.0 if i == j else 0.25 + 0.1 * ((i + j) % 3)
+                        A[i, j] = rng.standard_normal() * (1.0 if i != j else 0.3)
+    M = csr_matrix(M)
+    M = (M + M.T) * 0.5
+    return csr_matrix(M), csr_matrix(A)
+
+
+@pytest.mark.parametrize("N", [6, 23])
+def test_generic_pattern_width_9(hp, N):
+    from oracle import fct as ofct
+    rng = np.random.default_rng(N)
+    M, A = nine_point_problem(N, rng)
+    n = N * N
+    ml = np.asarray(M.sum(axis=1)).ravel()
+    ML = diags(ml).tocsr()
+    u_n = rng.random(n)
+    rhs = 0.1 * rng.standard_normal(n)
+    Nf = 0.05 * M
+    dt = 0.02
+    info = {}
+    u = hp.FCT_alg_ref(A, rhs, u_n, dt, n, M, ML, None, non_flux_mat=Nf, info=info)
+    uo = ofct.fct_step(A, rhs, u_n, dt, n, M, ML, None, non_flux_mat=Nf)
+    assert rel(u, uo) < 1e-9, info
+    y = hp.ChebSI(rhs, M, M.diagonal(), 7, 0.5, 2)
+    assert rel(y, ofct.chebsi(rhs, M, M.diagonal(), 7, 0.5, 2)) < 1e-13
+
+
+@pytest.mark.parametrize("nc", [1, 2, 3])
+def test_tiny_meshes(hp, nc):
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler, row_lump_diag
+    from oracle import fct as ofct, traj as otraj
+    mesh = SquareMesh(0, 1, nc)
+    asm = P1Assembler(mesh)
+    M = asm.mass()
+    n = mesh.nodes
+    ML = diags(row_lump_diag(M)).tocsr()
+    rng = np.random.default_rng(nc)
+    A = -(asm.convection(otraj.rotation_wind(3.0)) + asm.drift1(rng.random(n)))
+    u_n = rng.random(n)
+    u = hp.FCT_alg_ref(A, np.zeros(n), u_n, 1e-2, n, M, ML, None)
+    assert rel(u, ofct.fct_step(A, np.zeros(n), u_n, 1e-2, n, M, ML, None)) < 1e-10
+    # trajectories on the same tiny mesh, both DoF orders (tile kernels with a single, clipped patch)
+    solvers = importlib.import_module("fem-fct-pdeco_amd.solvers")
+    Nt = 3
+    sb = otraj.SolidBody(asm, om=3.0)
+    ck = rng.random((Nt + 1) * n)
+    uo = np.zeros((Nt + 1) * n); uo[:n] = u_n
+    otraj.solidbody_forward(sb, ck, uo, n, Nt, 1e-2)
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(0, 1, nc), Nt, 1e-2, om=3.0)
+    ug = np.zeros((Nt + 1) * n); ug[:n] = u_n
+    prob.solve_state(ck, ug)
+    assert rel(ug, uo) < 1e-10
+    prob.close()
+
+
+def test_zero_state_and_zero_operator(hp):
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler, row_lump_diag
+    asm = P1Assembler(SquareMesh(-1, 1, 8))
+    M = asm.mass()
+    n = M.shape[0]
+    ML = diags(row_lump_diag(M)).tocsr()
+    Z = csr_matrix((n, n))
+    info = {}
+    u = hp.FCT_alg_ref(Z, np.zeros(n), np.zeros(n), 1e-3, n, M, ML, None, info=info)
+    assert np.array_equal(u, np.zeros(n)) and info["solver_resid"] == 0.0
+    u1 = hp.FCT_alg_ref(Z, np.zeros(n), np.ones(n), 1e-3, n, M, ML, None)
+    assert np.max(np.abs(u1 - 1.0)) < 1e-14          # zero operator: the state is kept
+
+
+def test_solver_failure_is_reported_not_hidden(hp):
+    """A sweep cap far below what the operator needs must raise, never return an unconverged state."""
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    from oracle import traj as otraj
+    from helpers_golden import load, fct_case
+    c = fct_case(load("fct_cases.npz"), "rot_N41")
+    Mc = c["M"].copy(); Mc.sort_indices()
+    Ac = c["A"].copy(); Ac.sort_indices()
+    for fusion in ((False, False), (True, False)):
+        ctx = hp.Context(0)
+        ctx.set_pattern_csr(Mc.indptr, Mc.indices)
+        ctx.set_mass(Mc.data, c["ml"])
+        ctx.set_fusion(*fusion)
+        ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 4)
+        with pytest.raises(hp.NotConverged):
+            ctx.fct_step_host(Ac.data, c["rhs"], c["u_n"], c["dt"])
+        ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 400)
+        u, info = ctx.fct_step_host(Ac.data, c["rhs"], c["u_n"], c["dt"])
+        assert rel(u, c["u_np1"]) < 1e-9 and not (info["flags"] & hp.FLAG_SOLVER_BUDGET)
+        ctx.close()
+    solvers = importlib.import_module("fem-fct-pdeco_amd.solvers")
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1, 1, 16), 4, 2e-3)
+    prob.ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 3)
+    n = prob.n
+    uk = np.zeros(5 * n); uk[:n] = np.random.default_rng(0).random(n)
+    with pytest.raises(hp.NotConverged):
+        prob.solve_state(np.ones(5 * n), uk)
+    prob.close()
+    with pytest.raises(ValueError):
+        hp.Context(0).set_solver(7, 1e-13, 10)
