@@ -125,6 +125,7 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
         TilePlan tp;
         ctx->bigpart_count = 0;
         if (femfct_tile_plan(ctx, &tp, false) && femfct_tile_big(ctx, tp)) {
+            // covers the 32-patch grid and the (coarser) 64-patch grid
             ctx->bigpart_count = (int64_t)tp.tiles * tp.tiles;
             A_(d_bigpart, (size_t)batch * ctx->bigpart_count);
         }
@@ -208,6 +209,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_EXACT")) ctx->exact_iters = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
     if (const char* e = getenv("FEMFCT_STEPS_PER_GRAPH")) ctx->steps_per_graph = std::max(1, atoi(e));
     return femfct_strip_init(ctx);
 }

@@ -65,6 +65,7 @@ struct femfct_ctx {
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always
     bool fuse_end = true;       // log + level advance done by the last workgroup of the step's final kernel
     bool fuse_dudt = true;      // du/dt rhs + first Chebyshev iterations in one tile launch (small grids)
     bool exact_iters = false;   // last fused launch logs per-sweep residuals (exact sweep count; measured 10 % slower)
@@ -178,6 +179,14 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
 int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch);
+int femfct_tile4_init(femfct_ctx* ctx);
+bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
+int femfct_tile4_tiles(const femfct_ctx* ctx);
+int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
+                                int g_build, int32_t batch);
+int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
+                              int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
+                              double* bufB0, double* bufB1, int32_t batch);
 // number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
 int femfct_fused_k(const femfct_ctx* ctx);
 // sweep-budget policy (sweeps to enqueue for the next step sequence)

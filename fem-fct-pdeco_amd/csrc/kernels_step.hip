@@ -444,6 +444,13 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
     std::vector<double> om;
     cheb_omegas(iters, lmin, lmax, om);
     const double md_scale = (lmin + lmax) / 2.0;
+    if (femfct_tile4_wanted(ctx, batch)) {
+        if (first_done_in_y1)
+            return femfct_enqueue_tile4_cheb(ctx, b, ctx->d_y1, nullptr, y_out, 2, iters, om.data(), md_scale, ctx->d_y0,
+                                             ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
+        return femfct_enqueue_tile4_cheb(ctx, b, nullptr, nullptr, y_out, 1, iters, om.data(), md_scale, ctx->d_y0,
+                                         ctx->d_y2, ctx->d_y1, ctx->d_rp, batch);
+    }
     TilePlan tp;
     if (femfct_tile_plan(ctx, &tp, false)) {
         if (first_done_in_y1)
@@ -489,7 +496,16 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     const bool tiles = femfct_tile_plan(ctx, &tp, false, budget) && (!femfct_tile_big(ctx, tp) || ctx->d_bigpart);
     const bool strips = !tiles && femfct_strip_plan(ctx, &pl);
     int units = budget, part_count = 0, ipu = 1, exact_k = 0;
-    if (tiles) {
+    const bool tile4 = tiles && femfct_tile4_wanted(ctx, batch);
+    if (tile4) {
+        const int t4 = femfct_tile4_tiles(ctx);
+        const bool big4 = (int64_t)t4 * t4 > FEMFCT_MAX_PARTIALS;
+        units = (budget + 7) / 8;
+        part_count = big4 ? -1 : t4 * t4;
+        ipu = 8;
+        for (int s = 0; s < units; ++s)
+            femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
+    } else if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
         ipu = tp.K;
@@ -510,7 +526,7 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     }
     // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
     double* ulow = ctx->d_b;
-    if (tiles && !femfct_tile_big(ctx, tp) && ctx->fuse_dudt) {
+    if (tiles && !tile4 && !femfct_tile_big(ctx, tp) && ctx->fuse_dudt) {
         std::vector<double> om;
         cheb_omegas(20, 0.5, 2.0, om);
         femfct_enqueue_tile_dudt_cheb(ctx, A, rhs, rhs_bstride, ulow, units, part_count, ipu, exact_k, 20, om.data(), 1.25,

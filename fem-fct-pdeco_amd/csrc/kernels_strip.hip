@@ -246,7 +246,7 @@ int femfct_strip_init(femfct_ctx* ctx) {
     // > 64 KB of dynamic LDS needs the attribute
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_strip_cheb<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * STRIP_T * 8));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_strip_cheb<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * STRIP_T * 8));
-    return FEMFCT_OK;
+    return femfct_tile4_init(ctx);
 }
 
 int femfct_enqueue_strip_jacobi(femfct_ctx* ctx, const StripPlan& pl, const double* L, const double* b, double* xa,
@@ -843,4 +843,263 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, VecRef rhs, 
     // remaining iterations K+2 .. iters; inputs (mid, old) = (y0, y2); scratch pair (y1, rp) then (y0, y2)
     return femfct_enqueue_tile_cheb(ctx, tp, ctx->d_rdu, ctx->d_y0, ctx->d_y2, ctx->d_du, K + 2, iters, omegas, md_scale,
                                     ctx->d_y1, ctx->d_rp, ctx->d_y0, ctx->d_y2, batch);
+}
+
+// ===========================================================================================
+// Bandwidth-regime tiles: 64 x 64 patch, 48 x 48 tile + halo 8, four nodes per thread (1024
+// threads).  Each matrix row loaded from HBM is used for 8 sweeps and the halo re-read drops from
+// 4x (32-patch) to 1.78x: ~17 B of HBM traffic per row and sweep instead of ~35 (one-sweep
+// kernels: 104).  Used for large grids and for large batches of small trajectories.
+// ===========================================================================================
+#define T4_L 64
+#define T4_LD 65
+#define T4_H 8
+#define T4_T 48
+#define T4_BUF ((T4_L + 2) * T4_LD)   // one zero row above and below: neighbour offsets never leave the buffer
+
+namespace {
+
+// Per-node state kept small (four nodes per thread): neighbours are addressed as self + constant
+// offset.  A neighbour outside the grid has a zero matrix entry and lands on a zero pad element or
+// on another patch node (finite), so no clamping is needed.
+struct Tile4Node {
+    int i, self, kvalid;
+    bool inside, owned;
+};
+
+__device__ __forceinline__ Tile4Node tile4_node(int N, int q) {
+    Tile4Node g;
+    const int lx = (threadIdx.x & 31) + 32 * (q & 1), ly = (threadIdx.x >> 5) + 32 * (q >> 1);
+    const int x0 = blockIdx.x * T4_T - T4_H, y0 = blockIdx.y * T4_T - T4_H;
+    const int gx = x0 + lx, gy = y0 + ly;
+    g.inside = gx >= 0 && gx < N && gy >= 0 && gy < N;
+    g.i = g.inside ? gy * N + gx : 0;
+    g.owned = g.inside && lx >= T4_H && lx < T4_H + T4_T && ly >= T4_H && ly < T4_H + T4_T;
+    int kv = 1 << 20;
+    if (x0 > 0) kv = min(kv, lx);
+    if (x0 + T4_L - 1 < N - 1) kv = min(kv, T4_L - 1 - lx);
+    if (y0 > 0) kv = min(kv, ly);
+    if (y0 + T4_L - 1 < N - 1) kv = min(kv, T4_L - 1 - ly);
+    g.kvalid = g.inside ? kv : 0;
+    g.self = (ly + 1) * T4_LD + lx;
+    return g;
+}
+
+__device__ __forceinline__ int t4_off(int s) {   // slots E, NE, N, W, SW, S
+    return (s == 0) ? 1 : (s == 1) ? T4_LD + 1 : (s == 2) ? T4_LD : (s == 3) ? -1 : (s == 4) ? -T4_LD - 1 : -T4_LD;
+}
+
+__device__ __forceinline__ void t4_zero(double* buf, int count) {
+    for (int k = threadIdx.x; k < count; k += blockDim.x) buf[k] = 0.0;
+}
+
+// BIG as in k_tile_jacobi: residual partials via k_reduce_resid when the grid has more workgroups
+// than in-kernel partials
+template <int BIG>
+__global__ void __launch_bounds__(STRIP_T)
+k_tile4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
+               double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
+               int g_build, double rel_tol, double* __restrict__ bigpart) {
+    constexpr int W = 7;
+    extern __shared__ double lds[];
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    double bnorm;
+    if (launch == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        if (wg == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rmax = BIG ? ctl->rs[(launch - 1) & 1]
+                          : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        if (rmax <= rel_tol * bnorm) {
+            if (wg == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
+                ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
+    double* xout = ((launch & 1) ? xa_ : xb_) + voff;
+    double* cur = lds;
+    double* nxt = lds + T4_BUF;
+    t4_zero(lds, 2 * T4_BUF);
+    __syncthreads();
+    Tile4Node g[4];
+    double lv[4][W - 1], dg[4], rdg[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        g[q] = tile4_node(N, q);
+        dg[q] = 1.0; rdg[q] = 1.0; bv[q] = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) lv[q][s] = 0.0;
+        if (g[q].inside) {
+            dg[q] = L[g[q].i];
+            rdg[q] = 1.0 / dg[q];
+#pragma unroll
+            for (int s = 1; s < W; ++s) lv[q][s - 1] = L[(int64_t)s * n + g[q].i];
+            bv[q] = b_[voff + g[q].i];
+            cur[g[q].self] = xin[g[q].i];
+        }
+    }
+    __syncthreads();
+    double rmax = 0.0;
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double xn = cur[g[q].self];
+            if (k < g[q].kvalid) {
+                double acc = bv[q];
+#pragma unroll
+                for (int s = 0; s < W - 1; ++s) acc -= lv[q][s] * cur[g[q].self + t4_off(s)];
+                if (k == K - 1 && g[q].owned) rmax = fmax(rmax, fabs(acc - dg[q] * xn));
+                xn = acc * rdg[q];
+            }
+            if (g[q].inside) nxt[g[q].self] = xn;
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (g[q].owned) xout[g[q].i] = cur[g[q].self];
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) {
+        if (BIG) bigpart[(int64_t)bz * nwg + wg] = rmax;
+        else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+    }
+}
+
+__global__ void __launch_bounds__(STRIP_T)
+k_tile4_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
+             const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
+             CheOmegas om, double md_scale) {
+    constexpr int W = 7;
+    extern __shared__ double lds[];
+    double* y_old = lds;
+    double* y_mid = lds + T4_BUF;
+    double* y_new = lds + 2 * T4_BUF;
+    const int64_t voff = (int64_t)blockIdx.z * n;
+    t4_zero(lds, 3 * T4_BUF);
+    __syncthreads();
+    Tile4Node g[4];
+    double mv[4][W - 1], md[4], rmd[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        g[q] = tile4_node(N, q);
+        md[q] = 1.0; rmd[q] = 1.0; bv[q] = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) mv[q][s] = 0.0;
+        if (g[q].inside) {
+            md[q] = M[g[q].i];
+            rmd[q] = 1.0 / (md_scale * md[q]);
+#pragma unroll
+            for (int s = 1; s < W; ++s) mv[q][s - 1] = M[(int64_t)s * n + g[q].i];
+            bv[q] = b_[voff + g[q].i];
+            if (ymid_) y_mid[g[q].self] = ymid_[voff + g[q].i];
+            if (yold_) y_old[g[q].self] = yold_[voff + g[q].i];
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double ymv = y_mid[g[q].self];
+            double yn = ymv;
+            if (k < g[q].kvalid) {
+                double acc = md[q] * ymv;
+#pragma unroll
+                for (int s = 0; s < W - 1; ++s) acc += mv[q][s] * y_mid[g[q].self + t4_off(s)];
+                const double z = (bv[q] - acc) * rmd[q];
+                const double yov = y_old[g[q].self];
+                yn = om.w[k] * (z + ymv - yov) + yov;
+            }
+            if (g[q].inside) y_new[g[q].self] = yn;
+        }
+        __syncthreads();
+        double* t = y_old; y_old = y_mid; y_mid = y_new; y_new = t;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (g[q].owned) {
+            omid_[voff + g[q].i] = y_mid[g[q].self];
+            if (oold_) oold_[voff + g[q].i] = y_old[g[q].self];
+        }
+}
+
+}  // namespace
+
+int femfct_tile4_init(femfct_ctx* ctx) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tile4_jacobi<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF * 8));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tile4_jacobi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF * 8));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tile4_cheb, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T4_BUF * 8));
+    return FEMFCT_OK;
+}
+
+// bandwidth regime: the mesh (times the batch) is large enough that traffic, not launch latency, rules
+bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch) {
+    if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
+    if (ctx->tile4_mode == 0) return false;
+    if (ctx->tile4_mode == 2) return true;
+    return (int64_t)ctx->n * batch >= 400000;
+}
+
+int femfct_tile4_tiles(const femfct_ctx* ctx) { return (ctx->N + T4_T - 1) / T4_T; }
+
+int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
+                                int g_build, int32_t batch) {
+    const int t = femfct_tile4_tiles(ctx);
+    const bool big = (int64_t)t * t > FEMFCT_MAX_PARTIALS;
+    dim3 grid(t, t, batch);
+    const size_t lds = (size_t)2 * T4_BUF * 8;
+    femfct_prof_begin(ctx, KC_JACOBI);
+    if (big) {
+        hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
+                           ctx->d_ctl, launch, T4_H, g_build, ctx->rel_tol, ctx->d_bigpart);
+        hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
+                           ctx->d_ctl, launch);
+    } else {
+        hipLaunchKernelGGL(k_tile4_jacobi<0>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
+                           ctx->d_ctl, launch, T4_H, g_build, ctx->rel_tol, (double*)nullptr);
+    }
+    femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
+int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
+                              int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
+                              double* bufB0, double* bufB1, int32_t batch) {
+    const int t = femfct_tile4_tiles(ctx);
+    const size_t lds = (size_t)3 * T4_BUF * 8;
+    const double* mid = in_mid;
+    const double* old = in_old;
+    int which = 0;
+    for (int k0 = k_first; k0 <= k_last; k0 += T4_H) {
+        int k1 = std::min(k_last + 1, k0 + T4_H);
+        CheOmegas om;
+        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas[k - 1];
+        const bool last = (k1 == k_last + 1);
+        double* omid = last ? y_out : (which ? bufB0 : bufA0);
+        double* oold = last ? nullptr : (which ? bufB1 : bufA1);
+        femfct_prof_begin(ctx, KC_CHEB);
+        hipLaunchKernelGGL(k_tile4_cheb, dim3(t, t, batch), dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
+                           old, omid, oold, k1 - k0, om, md_scale);
+        femfct_prof_end(ctx);
+        mid = omid;
+        old = oold;
+        which ^= 1;
+    }
+    return FEMFCT_OK;
 }

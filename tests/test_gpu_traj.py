@@ -238,11 +238,11 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
     prob.close()
 
 
-@pytest.mark.parametrize("nc,order", [(40, 0), (40, 1), (767, 0)])
+@pytest.mark.parametrize("nc,order", [(40, 0), (40, 1), (767, 0), (2303, 0)])
 def test_fused_kernels_agree_with_one_sweep_kernels(hp, solvers, nc, order):
-    """Strip / tile multi-sweep kernels (incl. the large-grid tile path with the separate residual
-    reduce kernel at 768 x 768 nodes) against the plain one-sweep kernels on the same inputs."""
-    Nt = 3
+    """Strip / tile multi-sweep kernels (768^2 nodes: 64-patch tiles; 2304^2 nodes: 64-patch tiles with
+    the separate residual-reduce kernel) against the plain one-sweep kernels on the same inputs."""
+    Nt = 3 if nc < 2000 else 1
     mesh = hp.SquareMeshP1(-1, 1, nc)
     n = mesh.nodes
     dt = 1e-3 * (2.0 / nc) / 0.05
@@ -262,4 +262,30 @@ def test_fused_kernels_agree_with_one_sweep_kernels(hp, solvers, nc, order):
         outs.append(uk.copy())
     assert rel(outs[1], outs[0]) < 1e-11
     assert rel(outs[2], outs[0]) < 1e-11
+    prob.close()
+
+
+def test_large_batch_uses_bandwidth_tiles_and_matches_single(hp, solvers):
+    """n * batch >= 400k switches to the 64 x 64-patch kernels (four nodes per thread)."""
+    rng = np.random.default_rng(9)
+    nc, Nt, dt, B = 80, 2, 1e-3, 64
+    mesh = hp.SquareMeshP1(-1, 1, nc)
+    n = mesh.nodes
+    prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=B, order=hp.ORDER_VERTEX)
+    tl = (Nt + 1) * n
+    x, y = mesh.coordinates()
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    cks = 1.0 + rng.random((B, tl))
+    c = prob.ctx.array(cks.reshape(-1))
+    init = np.zeros((B, tl))
+    init[:, :n] = u0
+    u = prob.ctx.array(init.reshape(-1))
+    prob.forward(c, u, batch=B)
+    out = u.download().reshape(B, tl)
+    assert not np.any(prob.solver_log(B)["flags"] & hp.FLAG_SOLVER_BUDGET)
+    for b in (0, 17, 63):
+        uk = np.zeros(tl)
+        uk[:n] = u0
+        prob.solve_state(cks[b], uk)          # batch 1: latency-regime kernels
+        assert rel(out[b], uk) < 1e-11
     prob.close()
