@@ -1053,7 +1053,7 @@ bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch) {
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
     if (ctx->tile4_mode == 0) return false;
     if (ctx->tile4_mode == 2) return true;
-    return (int64_t)ctx->n * batch >= 400000;
+    return (int64_t)ctx->n * batch >= 150000;   // measured crossover at n = 6561: batch ~ 24
 }
 
 int femfct_tile4_tiles(const femfct_ctx* ctx) { return (ctx->N + T4_T - 1) / T4_T; }

@@ -266,7 +266,7 @@ def test_fused_kernels_agree_with_one_sweep_kernels(hp, solvers, nc, order):
 
 
 def test_large_batch_uses_bandwidth_tiles_and_matches_single(hp, solvers):
-    """n * batch >= 400k switches to the 64 x 64-patch kernels (four nodes per thread)."""
+    """n * batch >= 150k switches to the 64 x 64-patch kernels (four nodes per thread)."""
     rng = np.random.default_rng(9)
     nc, Nt, dt, B = 80, 2, 1e-3, 64
     mesh = hp.SquareMeshP1(-1, 1, nc)

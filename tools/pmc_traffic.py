@@ -17,7 +17,7 @@ import re
 import statistics
 import sys
 
-CLASS = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_tile_jacobi": "jacobi", "k_strip_jacobi": "jacobi",
+CLASS = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_tile_jacobi": "jacobi", "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb", "k_strip_jacobi": "jacobi",
          "k_dudt_rhs": "dudt_rhs", "k_cheb": "cheb", "k_tile_cheb": "cheb", "k_strip_cheb": "cheb",
          "k_flux": "flux", "k_tile_flux_limit": "flux", "k_limit": "limit", "k_ops_solidbody": "assemble"}
 
@@ -41,7 +41,7 @@ def load(path, counter, min_grid):
 
 def main():
     fpath, wpath, n, prefix = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    min_grid = n // 2          # work-items: only the large-mesh launches
+    min_grid = n // 8          # work-items: only the large-mesh launches (tile kernels: up to 4 nodes/thread)
     fa = load(fpath, "FETCH_SIZE", min_grid)
     wa = load(wpath, "WRITE_SIZE", min_grid)
     rows, traffic = [], {}
