@@ -257,7 +257,13 @@ def roofline(hp, solvers, n_cells, steps, device_id):
         kernels[k] = e
     dom_name = max(("jacobi", "cheb"), key=lambda k: kernels[k]["total_ms"])
     dom = kernels[dom_name]
-    out = {"bound": "hbm", "kernel": f"{dom_name} ({'8-sweep tile-fused' if dom['sweeps_per_launch'] > 1.5 else 'one sweep per launch'})",
+    if dom["sweeps_per_launch"] > 1.5:
+        sym = {"jacobi": "k_tile4_jacobi<0>", "cheb": "k_tile4_cheb"}[dom_name] if n >= 150000 else \
+              {"jacobi": "k_tile_jacobi<H,0,0>", "cheb": "k_tile_cheb<H>"}[dom_name]
+        label = f"{sym} (tile-fused, {dom['sweeps_per_launch']:.1f} sweeps per launch)"
+    else:
+        label = {"jacobi": "k_jacobi<7,256,*>", "cheb": "k_cheb<7,256,*>"}[dom_name] + " (one sweep per launch)"
+    out = {"bound": "hbm", "kernel": label,
            "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
            "traffic": dom.get("traffic_bytes_per_launch"), "hbm_frac": dom.get("hbm_frac"),
            "workload": f"synthetic square mesh {n_cells + 1}x{n_cells + 1} (n={n}), vertex order, same CFL as C2",
