@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--roofline-cells", type=int, default=2048, help="cells per side of the roofline mesh (0: skip)")
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=20, help="forward+adjoint oracle steps each (0: skip)")
+    ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,6 +193,19 @@ def main():
     # ------------------------------------------------------------ roofline mesh
     if rank == 0 and args.roofline_cells > 0:
         result["roofline"] = roofline(hp, solvers, args.roofline_cells, args.roofline_steps, local_rank)
+    if rank == 0 and args.pgd_iters > 0:
+        # the full optimisation loop of configs[1] (finaltime_Garvie.py:164-330), everything in HBM;
+        # speculative = all 10 Armijo trial steps as one batch of independent trajectories
+        pg = {}
+        for spec in (True, False):
+            t0 = time.perf_counter()
+            _, _, _, hist = solvers.pgd_solidbody_finaltime(prob, to_dev(u0), to_dev(uhat), np.ones(tl), 1.0, 0.0, 5.0,
+                                                            args.pgd_iters, speculative=spec)
+            dt_it = (time.perf_counter() - t0) / len(hist["cost"])
+            pg["speculative" if spec else "sequential"] = {
+                "s_per_pgd_iteration": dt_it, "armijo_trials": hist["armijo_k"], "cost": hist["cost"][-1]}
+        pg["cost_rel_diff"] = abs(pg["speculative"]["cost"] - pg["sequential"]["cost"]) / abs(pg["sequential"]["cost"])
+        result["pgd_c2"] = pg
     if rank == 0 and args.cpu_sample > 0:
         result["cpu_baseline"] = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample)
     if dist is not None:

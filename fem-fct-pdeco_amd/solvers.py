@@ -132,7 +132,8 @@ def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower,
 
     Everything stays in HBM; the host sees scalars only.  ``speculative=True`` evaluates all
     ``max_armijo`` trial steps as one batch of independent trajectories (same launches, B = max_armijo)
-    and picks the first accepted one -- the same iterate as the sequential search, bit for bit.
+    and picks the first accepted one -- the iterate of the sequential search (each trial trajectory is
+    the same computation; the states agree to the low-order solver tolerance, 1e-13).
     Returns ``(u, p, c, history)`` as NumPy arrays + a dict of per-iteration scalars."""
     ctx, n, Nt, dt, tl = prob.ctx, prob.n, prob.num_steps, prob.dt, prob.tlen
     B = int(max_armijo) if speculative else 1
