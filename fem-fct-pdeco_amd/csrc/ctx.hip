@@ -82,6 +82,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_scratch); ctx->scratch_count = 0;
     dev_free(&ctx->d_kry); dev_free(&ctx->d_kry_part);
     if (ctx->d_kry_ctl) { hipFree(ctx->d_kry_ctl); ctx->d_kry_ctl = nullptr; }
+    if (ctx->d_kry_ctl2) { hipFree(ctx->d_kry_ctl2); ctx->d_kry_ctl2 = nullptr; }
     if (ctx->d_klog) { hipFree(ctx->d_klog); ctx->d_klog = nullptr; }
     ctx->kry_batch = 0;
     dev_free(&ctx->d_trMat); dev_free(&ctx->d_trBase); dev_free(&ctx->d_trBase2); dev_free(&ctx->d_trRhs2); dev_free(&ctx->d_trTmp);
@@ -110,6 +111,10 @@ void femfct_drop_graphs(femfct_ctx* ctx) {
 }
 
 int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
+    if (ctx->solver == FEMFCT_SOLVER_BICGSTAB) {
+        int rk = femfct_ensure_krylov_ws(ctx, batch);
+        if (rk != FEMFCT_OK) return rk;
+    }
     if (batch <= ctx->ws_batch) return FEMFCT_OK;
     femfct_drop_graphs(ctx);
     size_t nv = (size_t)batch * ctx->n, nm = nv * ctx->W;
@@ -289,6 +294,7 @@ int femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters
     ctx->rel_tol = rel_tol;
     ctx->max_iters = max_iters;
     if (ctx->sweep_budget > max_iters) ctx->sweep_budget = max_iters;
+    ctx->kind_budget.clear();
     femfct_drop_graphs(ctx);
     return FEMFCT_OK;
 }
@@ -508,7 +514,6 @@ int femfct_fct_step(femfct_ctx* ctx, const double* A_ell, const double* N_ell, i
     ARG_TRY(ctx, ctx->have_mass, "mass matrix not set (femfct_set_mass / femfct_set_mesh_square)");
     ARG_TRY(ctx, A_ell && u_n && u_out, "null argument");
     ARG_TRY(ctx, batch >= 1 && dt > 0, "batch must be >= 1 and dt > 0");
-    ARG_TRY(ctx, ctx->solver == FEMFCT_SOLVER_JACOBI, "only the Jacobi low-order solver is wired into the step");
     int rc = femfct_ensure_workspace(ctx, batch);
     if (rc != FEMFCT_OK) return rc;
     return launch_step(ctx, A_ell, N_ell, N_shared, rhs, u_n, dt, u_out, batch);
@@ -550,7 +555,7 @@ int femfct_fct_step_host(femfct_ctx* ctx, const double* A_csr, const double* N_c
     if (rhs) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_hrhs, rhs, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_hu, u_n, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     femfct_step_info local;
-    for (int attempt = 0;; ++attempt) {
+    for (;;) {
         rc = femfct_fct_step(ctx, ctx->d_hA, N_csr ? ctx->d_hN : nullptr, 0, rhs ? ctx->d_hrhs : nullptr, ctx->d_hu,
                              dt, ctx->d_hout, 1);
         if (rc != FEMFCT_OK) return rc;

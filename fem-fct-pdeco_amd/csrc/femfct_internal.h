@@ -114,6 +114,7 @@ struct femfct_ctx {
     double* d_kry = nullptr;        // 9 vectors [9][kry_batch*n]
     double* d_kry_part = nullptr;
     void* d_kry_ctl = nullptr;      // KrylovCtl[kry_batch]
+    void* d_kry_ctl2 = nullptr;     // KrylovCtl[kry_batch] of the FCT step's own low-order solve (solver = BICGSTAB)
     double kry_tol = 1e-13;
     int kry_max_iters = 2000;
     int kry_budget = 40;            // adaptive
@@ -143,6 +144,7 @@ int femfct_fail(femfct_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch);
+int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch);
 void femfct_drop_graphs(femfct_ctx* ctx);
 void femfct_release_pattern(femfct_ctx* ctx);
 int femfct_round_budget(const femfct_ctx* ctx, int b);

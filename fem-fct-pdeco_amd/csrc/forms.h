@@ -50,5 +50,9 @@ struct KrylovCtl {
     double rho2[2];      // rho of iteration it at [it & 1] (two slots: no same-kernel read/write)
     double alpha, omega;
 };
+// lowsolve = true: the low-order solve of the FCT step (own control blocks, tolerance rel_tol; the
+// result is reported through StepCtl by femfct_enqueue_kry_to_stepctl)
 int femfct_enqueue_bicgstab(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
-                            int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget);
+                            int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget,
+                            bool lowsolve = false);
+int femfct_enqueue_kry_to_stepctl(femfct_ctx* ctx, int g_build, int32_t batch);

@@ -208,14 +208,6 @@ __global__ void k_drift_gradient_rhs(int n, int N, int nc, double h, const int32
     }
 }
 
-__global__ void k_advance(int32_t* level, int delta) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *level += delta;
-}
-
-__global__ void k_set_level(int32_t* level, int value) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *level = value;
-}
-
 // out = a - b elementwise (terminal condition p(T) = uhat_T - u(T), helpers.py:1020)
 __global__ void k_axpby(int64_t count, double alpha, const double* __restrict__ a, double beta,
                         const double* __restrict__ b, double* __restrict__ out) {
@@ -253,16 +245,6 @@ int femfct_enqueue_mass_diff(femfct_ctx* ctx, VecRef a, int64_t a_bstride, VecRe
     LaunchGeom g = femfct_geom(ctx, batch);
     hipLaunchKernelGGL(k_mass_diff, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->W, ctx->d_cols, ctx->d_M, a,
                        a_bstride, b, b_bstride, out);
-    return FEMFCT_OK;
-}
-
-int femfct_enqueue_advance(femfct_ctx* ctx, int32_t* level, int delta) {
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ctx->stream, level, delta);
-    return FEMFCT_OK;
-}
-
-int femfct_enqueue_set_level(femfct_ctx* ctx, int32_t* level, int value) {
-    hipLaunchKernelGGL(k_set_level, dim3(1), dim3(64), 0, ctx->stream, level, value);
     return FEMFCT_OK;
 }
 

@@ -211,6 +211,38 @@ __global__ void k_kry_finish(int n, KryVecs kv, VecRef out_ref, int64_t out_bs, 
 
 }  // namespace
 
+namespace {
+// Low-order solve by BiCGStab: publish its outcome in the step's control block (what the Jacobi
+// sweeps / finalize_solve do otherwise) and evaluate the row-sum diagnostic from k_build_low's partials.
+__global__ void k_kry_to_stepctl(const KrylovCtl* __restrict__ kc, StepCtl* __restrict__ sc, const double* __restrict__ part,
+                                 int g_build) {
+    __shared__ double smem[32];
+    const int bz = blockIdx.x;
+    const double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    double bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+    double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+    if (threadIdx.x == 0) {
+        StepCtl* c = sc + bz;
+        c->bnorm = bnorm;
+        c->min_rowsum = rsmin;
+        c->iters = kc[bz].iters;
+        c->resid = kc[bz].resid;
+        c->done = 1;
+        c->parity = 0;
+        int f = c->flags;
+        if (!(rsmin > 0.0)) f |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        if ((kc[bz].flags & FEMFCT_FLAG_SOLVER_BUDGET) || !(kc[bz].resid == kc[bz].resid)) f |= FEMFCT_FLAG_SOLVER_BUDGET;
+        c->flags = f;
+    }
+}
+}  // namespace
+
+int femfct_enqueue_kry_to_stepctl(femfct_ctx* ctx, int g_build, int32_t batch) {
+    hipLaunchKernelGGL(k_kry_to_stepctl, dim3(batch), dim3(256), 0, ctx->stream, (const KrylovCtl*)ctx->d_kry_ctl2, ctx->d_ctl,
+                       ctx->d_part, g_build);
+    return FEMFCT_OK;
+}
+
 int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch) {
     if (batch <= ctx->kry_batch) return FEMFCT_OK;
     femfct_drop_graphs(ctx);
@@ -223,31 +255,36 @@ int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_kry_part, sizeof(double) * (size_t)batch * 6 * FEMFCT_MAX_PARTIALS));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_kry_ctl, sizeof(KrylovCtl) * (size_t)batch));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_kry_ctl, 0, sizeof(KrylovCtl) * batch, ctx->stream));
+    if (ctx->d_kry_ctl2) hipFree(ctx->d_kry_ctl2);
+    ctx->d_kry_ctl2 = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_kry_ctl2, sizeof(KrylovCtl) * (size_t)batch));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_kry_ctl2, 0, sizeof(KrylovCtl) * batch, ctx->stream));
     ctx->kry_batch = batch;
     return FEMFCT_OK;
 }
 
 int femfct_enqueue_bicgstab(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
-                            int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget) {
+                            int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget, bool lowsolve) {
     const size_t nv = (size_t)ctx->kry_batch * ctx->n;
     KryVecs kv;
     double* base = ctx->d_kry;
     kv.x = base; kv.r = base + nv; kv.rh = base + 2 * nv; kv.p0 = base + 3 * nv; kv.p1 = base + 4 * nv;
     kv.v0 = base + 5 * nv; kv.v1 = base + 6 * nv; kv.s = base + 7 * nv; kv.t = base + 8 * nv;
     kv.part = ctx->d_kry_part;
-    kv.ctl = (KrylovCtl*)ctx->d_kry_ctl;
+    kv.ctl = (KrylovCtl*)(lowsolve ? ctx->d_kry_ctl2 : ctx->d_kry_ctl);
+    const double tol = lowsolve ? ctx->rel_tol : ctx->kry_tol;
     LaunchGeom g = femfct_geom(ctx, batch);
     hipStream_t st = ctx->stream;
     const int n = ctx->n, W = ctx->W;
     femfct_prof_begin(ctx, KC_OTHER);
     hipLaunchKernelGGL(k_kry_init, g.grid, g.block, 0, st, n, W, ctx->d_cols, mat, mat_shared, b, x0, x0_bs, kv);
     for (int it = 0; it < budget; ++it) {
-        hipLaunchKernelGGL(k_kry_a, g.grid, g.block, 0, st, n, W, ctx->d_cols, mat, mat_shared, kv, it, ctx->kry_tol);
+        hipLaunchKernelGGL(k_kry_a, g.grid, g.block, 0, st, n, W, ctx->d_cols, mat, mat_shared, kv, it, tol);
         hipLaunchKernelGGL(k_kry_b, g.grid, g.block, 0, st, n, W, ctx->d_cols, mat, mat_shared, kv, it);
         hipLaunchKernelGGL(k_kry_c, g.grid, g.block, 0, st, n, W, mat, mat_shared, kv, it);
     }
     // one more convergence test of the last residual happens in k_kry_finish
-    hipLaunchKernelGGL(k_kry_finish, g.grid, g.block, 0, st, n, kv, x_out, out_bs, budget, ctx->kry_tol);
+    hipLaunchKernelGGL(k_kry_finish, g.grid, g.block, 0, st, n, kv, x_out, out_bs, budget, tol);
     femfct_prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "bicgstab launch failed: %s", hipGetErrorString(e));

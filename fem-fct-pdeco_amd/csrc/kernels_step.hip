@@ -21,15 +21,13 @@
 #include "femfct_internal.h"
 #include "device_utils.h"
 #include "solve_ctl.h"
+#include "forms.h"
 
 #include <math.h>
 #include <stdlib.h>
 
 namespace {
 
-__device__ __forceinline__ const double* sel(const StepCtl* ctl, const double* xa, const double* xb) {
-    return ctl->parity ? xb : xa;
-}
 
 
 // Column index of slot s in row i.  IMP = 0: explicit ELL column table (any pattern / ordering).
@@ -497,7 +495,15 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     const bool strips = !tiles && femfct_strip_plan(ctx, &pl);
     int units = budget, part_count = 0, ipu = 1, exact_k = 0;
     const bool tile4 = tiles && femfct_tile4_wanted(ctx, batch);
-    if (tile4) {
+    if (ctx->solver == FEMFCT_SOLVER_BICGSTAB) {
+        // robust alternative for operators far from diagonal dominance: Jacobi-preconditioned BiCGStab
+        // from x0 = u^n into d_xa; outcome mirrored into StepCtl (done, parity 0)
+        int r = femfct_enqueue_bicgstab(ctx, ctx->d_L, 0, ctx->d_b, make_ref(ctx->d_xa), n, make_ref(ctx->d_xa), n, batch,
+                                        budget, true);
+        if (r != FEMFCT_OK) return r;
+        femfct_enqueue_kry_to_stepctl(ctx, (int)g.grid.x, batch);
+        units = 0;
+    } else if (tile4) {
         const int t4 = femfct_tile4_tiles(ctx);
         const bool big4 = (int64_t)t4 * t4 > FEMFCT_MAX_PARTIALS;
         units = (budget + 7) / 8;
@@ -524,7 +530,7 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
             LAUNCH_W(KC_JACOBI, k_jacobi, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb,
                      ctx->d_part, ctx->d_ctl, s, ctx->rel_tol);
     }
-    // u_L is copied to d_rp's neighbour buffer d_du? no: dedicated d_ulow = d_b is free now (b is dead)
+    // stable home of u_L for the flux/limit kernels: d_b (the low-order rhs is dead after the solve)
     double* ulow = ctx->d_b;
     if (tiles && !tile4 && !femfct_tile_big(ctx, tp) && ctx->fuse_dudt) {
         std::vector<double> om;

@@ -23,7 +23,6 @@ int femfct_enqueue_ops_solidbody(femfct_ctx* ctx, const double* Arot, VecRef c_r
                                  double sigma, double rot_scale, double bx, double by, double* A, int32_t batch);
 int femfct_enqueue_mass_diff(femfct_ctx* ctx, VecRef a, int64_t a_bstride, VecRef b, int64_t b_bstride, double* out,
                              int32_t batch);
-int femfct_enqueue_set_level(femfct_ctx* ctx, int32_t* level, int value);
 int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
                          double* out);
 

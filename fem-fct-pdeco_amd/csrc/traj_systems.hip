@@ -6,7 +6,6 @@
 // species] -> [log + advance level]; captured once as a hipGraph and replayed per step.
 #include "traj_common.h"
 
-int femfct_enqueue_set_level(femfct_ctx* ctx, int32_t* level, int value);
 
 namespace {
 

@@ -136,3 +136,52 @@ def test_solver_failure_is_reported_not_hidden(hp):
     prob.close()
     with pytest.raises(ValueError):
         hp.Context(0).set_solver(7, 1e-13, 10)
+
+
+@pytest.mark.parametrize("name", ["rot_N41", "schnak_N41", "rotdrift22_bigdt_N41"])
+def test_bicgstab_low_order_solver(hp, name):
+    """femfct_set_solver(FEMFCT_SOLVER_BICGSTAB): same step through the Krylov low-order solve."""
+    from helpers_golden import load, fct_case
+    c = fct_case(load("fct_cases.npz"), name)
+    pat = hp.fct_helpers._PatternCache.get_for(c["M"])     # values laid out on the pattern of M
+    ctx = pat.ctx
+    pat.set_mass(c["M"], c["ml"])
+    ctx.set_solver(hp.SOLVER_BICGSTAB, 1e-13, 200)
+    try:
+        u, info = ctx.fct_step_host(pat.values(c["A"]), c["rhs"], c["u_n"], c["dt"],
+                                    N_csr_vals=None if c["N"] is None else pat.values(c["N"]))
+    finally:
+        ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 400)
+    assert rel(u, c["u_np1"]) < 1e-9, info
+    assert bool(info["flags"] & hp.FLAG_MMATRIX_ROWSUM) == c["mmatrix_failed"]
+    assert not (info["flags"] & hp.FLAG_SOLVER_BUDGET) and info["solver_iters"] > 0
+
+
+def test_bicgstab_handles_a_time_step_jacobi_cannot(hp):
+    """dt 40x beyond the scheme's CFL-type bound: Jacobi needs > 400 sweeps (reported), BiCGStab solves it;
+    both are checked against the oracle's direct solve."""
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler, row_lump_diag
+    from oracle import fct as ofct, traj as otraj
+    mesh = SquareMesh(-1, 1, 24)
+    asm = P1Assembler(mesh)
+    M = asm.mass(); n = mesh.nodes
+    ML = diags(row_lump_diag(M)).tocsr()
+    A = -asm.convection(otraj.rotation_wind(np.pi / 40)) + 0.5 * asm.stiffness()
+    rng = np.random.default_rng(5)
+    u_n = rng.random(n)
+    dt = 0.2
+    uo = ofct.fct_step(A, np.zeros(n), u_n, dt, n, M, ML, None)
+    pat = hp.fct_helpers._PatternCache.get_for(M)
+    ctx = pat.ctx
+    pat.set_mass(M, row_lump_diag(M))
+    a = pat.values(A)
+    try:
+        ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 400)
+        with pytest.raises(hp.NotConverged):
+            ctx.fct_step_host(a, np.zeros(n), u_n, dt)
+        ctx.set_solver(hp.SOLVER_BICGSTAB, 1e-13, 400)
+        u, info = ctx.fct_step_host(a, np.zeros(n), u_n, dt)
+    finally:
+        ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 400)
+    assert rel(u, uo) < 1e-9, info
