@@ -61,8 +61,9 @@ typedef struct femfct_ctx femfct_ctx;
 #define FEMFCT_ORDER_FENICS 1         /* FEniCS CG1 dof order: rank of (ix-iy, iy) */
 
 /* low-order solver selection */
-#define FEMFCT_SOLVER_JACOBI   0      /* Jacobi sweeps, device-side convergence test */
-#define FEMFCT_SOLVER_BICGSTAB 1      /* Jacobi-preconditioned BiCGStab */
+#define FEMFCT_SOLVER_JACOBI   0      /* Jacobi sweeps, device-side convergence test (default; fused multi-sweep kernels) */
+#define FEMFCT_SOLVER_BICGSTAB 1      /* Jacobi-preconditioned BiCGStab: for operators far outside the scheme's
+                                         dt restriction, where Jacobi would need hundreds of sweeps */
 
 typedef struct femfct_step_info {
     int32_t flags;          /* FEMFCT_FLAG_* */
