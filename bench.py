@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=20, help="forward+adjoint oracle steps each (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
+    ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -193,6 +194,33 @@ def main():
     # ------------------------------------------------------------ roofline mesh
     if rank == 0 and args.roofline_cells > 0:
         result["roofline"] = roofline(hp, solvers, args.roofline_cells, args.roofline_steps, local_rank)
+    if rank == 0 and args.batched:
+        # the same sweep with B independent trajectories per launch (beta values / Armijo trials on one GPU)
+        result["batched"] = []
+        for Bx in [int(t) for t in args.batched.split(",") if t]:
+            cb = ctx.array(np.tile(to_dev(ck), Bx))
+            ib = np.zeros((Bx, tl))
+            ib[:, :n] = to_dev(u0)
+            ub, pb = ctx.array(ib.reshape(-1)), ctx.zeros(Bx * tl)
+            uhb = ctx.array(np.tile(to_dev(uhat), Bx))
+
+            def sweep():
+                prob.forward(cb, ub, batch=Bx)
+                prob.cost(ub, uhb, cb, beta, "finaltime", batch=Bx)
+                prob.adjoint(cb, ub, uhb, pb, "finaltime", batch=Bx)
+
+            for _ in range(2):
+                sweep()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                sweep()
+            ctx.synchronize()
+            el = (time.perf_counter() - t0) / 2
+            result["batched"].append({"batch_per_gpu": Bx, "value": 2 * Nt * Bx / el, "unit": "timesteps/s",
+                                      "ms_per_step": 1e3 * el})
+            for a in (cb, ub, pb, uhb):
+                a.free()
     if rank == 0 and args.pgd_iters > 0:
         # the full optimisation loop of configs[1] (finaltime_Garvie.py:164-330), everything in HBM;
         # speculative = all 10 Armijo trial steps as one batch of independent trajectories
