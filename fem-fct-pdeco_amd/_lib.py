@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfemfct.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_NOMEM = 0, 1, 2, 3, 4
-FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET = 1, 2
+FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV = 1, 2, 4, 8
 ORDER_VERTEX, ORDER_FENICS = 0, 1
 SOLVER_JACOBI, SOLVER_BICGSTAB = 0, 1
 ABI_VERSION = 1
@@ -105,6 +105,7 @@ SIGNATURES = {
     "femfct_ell_transpose": (C.c_int, [_p, _p, _p]),
     "femfct_axpby": (C.c_int, [_p, C.c_int64, _d, _p, _d, _p, _p]),
     "femfct_set_krylov": (C.c_int, [_p, _d, _i]),
+    "femfct_set_species_solver": (C.c_int, [_p, _i]),
     "femfct_bicgstab": (C.c_int, [_p, _p, _i, _p, _p, _p, _i, C.POINTER(StepInfo)]),
     "femfct_nonlinear_forward": (C.c_int, [_p, _p, _p, _p, _i, _d, _d, _i]),
     "femfct_nonlinear_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _i, _d, _d, _i]),

@@ -80,7 +80,8 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_ticket);
     ctx->tr_batch = 0; ctx->tr_steps = 0;
     dev_free(&ctx->d_scratch); ctx->scratch_count = 0;
-    dev_free(&ctx->d_kry); dev_free(&ctx->d_kry_part);
+    dev_free(&ctx->d_kry); dev_free(&ctx->d_kry_part); dev_free(&ctx->d_chs_om); dev_free(&ctx->d_chs_scale);
+    ctx->chs_om_cap = 0;
     if (ctx->d_kry_ctl) { hipFree(ctx->d_kry_ctl); ctx->d_kry_ctl = nullptr; }
     if (ctx->d_kry_ctl2) { hipFree(ctx->d_kry_ctl2); ctx->d_kry_ctl2 = nullptr; }
     if (ctx->d_klog) { hipFree(ctx->d_klog); ctx->d_klog = nullptr; }
@@ -215,6 +216,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
+    if (const char* e = getenv("FEMFCT_SPECIES_SOLVER")) ctx->species_solver = atoi(e);
     if (const char* e = getenv("FEMFCT_STEPS_PER_GRAPH")) ctx->steps_per_graph = std::max(1, atoi(e));
     return femfct_strip_init(ctx);
 }

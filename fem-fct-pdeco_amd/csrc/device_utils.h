@@ -23,6 +23,20 @@ __device__ __forceinline__ const double* vec_ptr(const VecRef& r) {
     return r.base + lv * r.stride;
 }
 
+// Optional overrides of the tile Chebyshev kernels (species solves inside trajectory sweeps): another
+// matrix than the mass matrix (per batch member), a level-indirected start iterate / destination.
+struct ChebIO {
+    const double* mat;      // null: the registered mass matrix
+    int64_t mat_bs;         // batch stride of mat (0: shared)
+    VecRef mid_ref;         // base null: use the plain pointer argument
+    int64_t mid_bs;
+    VecRef out_ref;
+    int64_t out_bs;
+    const double* om_dev;   // null: the by-value omega table; else omega_(k0+k) = om_dev[bz*om_bs + k0 + k]
+    int32_t om_bs, k0;
+    const double* scale_dev;   // null: md_scale argument; else per batch member
+};
+
 static inline VecRef make_ref(const double* p) { return VecRef{p, nullptr, 0, 0}; }
 static inline VecRef make_ref(const double* p, const int32_t* level, int64_t stride, int32_t off) {
     return VecRef{p, level, stride, off};

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <set>
 #include <tuple>
 
 #include "../../include/femfct.h"
@@ -119,6 +120,11 @@ struct femfct_ctx {
     int kry_max_iters = 2000;
     int kry_budget = 40;            // adaptive
     void* d_klog = nullptr;         // KrylovCtl[tr_steps * tr_batch]
+    int species_solver = 0;         // 0: Chebyshev where the tile plan applies (fallback BiCGStab), 1: BiCGStab
+    std::set<int> kind_cheb_off;    // sweep kinds whose Chebyshev iteration failed to contract
+    double* d_chs_om = nullptr;     // [kry_batch][chs_om_cap] omega tables
+    double* d_chs_scale = nullptr;  // [kry_batch] (lmin+lmax)/2
+    int chs_om_cap = 0;
     std::vector<char> h_klog;
     // extra trajectory operators
     double *d_trMat = nullptr, *d_trBase = nullptr, *d_trBase2 = nullptr;  // [B*W*n], [W*n], [W*n]
@@ -175,7 +181,8 @@ int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double
 bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl);   // more workgroups than in-kernel partials
 int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
-                             double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch);
+                             double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch,
+                             const struct ChebIO* io = nullptr);
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
                                    struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end);
 int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
@@ -188,7 +195,8 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
                                 int g_build, int32_t batch);
 int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
-                              double* bufB0, double* bufB1, int32_t batch);
+                              double* bufB0, double* bufB1, int32_t batch,
+                              const struct ChebIO* io = nullptr);
 // number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
 int femfct_fused_k(const femfct_ctx* ctx);
 // sweep-budget policy (sweeps to enqueue for the next step sequence)

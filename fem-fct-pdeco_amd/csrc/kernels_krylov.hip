@@ -244,8 +244,16 @@ int femfct_enqueue_kry_to_stepctl(femfct_ctx* ctx, int g_build, int32_t batch) {
 }
 
 int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch) {
-    if (batch <= ctx->kry_batch) return FEMFCT_OK;
+    const int om_cap = ctx->kry_max_iters + 16;
+    if (batch <= ctx->kry_batch && om_cap <= ctx->chs_om_cap) return FEMFCT_OK;
+    if (batch < ctx->kry_batch) batch = ctx->kry_batch;
     femfct_drop_graphs(ctx);
+    if (ctx->d_chs_om) hipFree(ctx->d_chs_om);
+    if (ctx->d_chs_scale) hipFree(ctx->d_chs_scale);
+    ctx->d_chs_om = nullptr; ctx->d_chs_scale = nullptr; ctx->chs_om_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chs_om, sizeof(double) * (size_t)batch * om_cap));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chs_scale, sizeof(double) * (size_t)batch));
+    ctx->chs_om_cap = om_cap;
     if (ctx->d_kry) hipFree(ctx->d_kry);
     if (ctx->d_kry_part) hipFree(ctx->d_kry_part);
     if (ctx->d_kry_ctl) hipFree(ctx->d_kry_ctl);
@@ -289,4 +297,197 @@ int femfct_enqueue_bicgstab(femfct_ctx* ctx, const double* mat, int32_t mat_shar
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "bicgstab launch failed: %s", hipGetErrorString(e));
     return FEMFCT_OK;
+}
+
+
+// ===========================================================================================
+// Chebyshev species solve: the same implicit systems as the BiCGStab above, for the structured
+// 7-point mesh in vertex order.  Dot-product free, so ten iterations run inside one tile launch
+// (k_tile_cheb / k_tile4_cheb with the system matrix instead of M): ~10x fewer launches per solve.
+//   spectrum of D^-1 Mat:  lambda_max <= 2 x (1 + safety) on the right-diagonal P1 mesh (element
+//   matrices of M, Ad and the weighted masses all satisfy Me <= 2 diag(Me)); lambda_min >= 0.5 min_i
+//   m_ii / a_ii because sym(Mat) >= M >= 0.5 diag(M).  The skew (convective) part only bends the
+//   spectrum into an ellipse around that interval; the residual check below decides, and the sweep
+//   falls back to BiCGStab when the iteration does not contract.
+// ===========================================================================================
+namespace {
+
+// one block per batch member: lambda_min bound, omega table (closed form of the three-term
+// recurrence w_1 = 1, w_{k+1} = 2 xi T_k(xi) / T_{k+1}(xi), xi = 1/rho).
+//   tau >= 0: Mat = M + tau*Ad + (terms with positive semi-definite symmetric part); then
+//     lambda_min >= lam_e * min_i (m_ii + tau k_ii) / a_ii,   lam_e = smallest eigenvalue of the element
+//     pencil (Me + tau Ke, diag(Me + tau Ke)) (element-by-element bound, host-computed);
+//   tau < 0 (structure unknown): lambda_min >= 0.5 min_i m_ii / a_ii.
+__global__ void k_chs_setup(int n, int W, const double* __restrict__ A_, int ashared, const double* __restrict__ Mdiag,
+                            const double* __restrict__ Kdiag, double tau, double lam_e, double lmax, int K,
+                            double* __restrict__ om, int om_bs, double* __restrict__ scale, KrylovCtl* __restrict__ ctl_) {
+    __shared__ double smem[32];
+    const int bz = blockIdx.x;
+    const double* A = A_ + (ashared ? 0 : (int64_t)bz * W * n);
+    double mn = INFINITY;
+    if (tau >= 0.0)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) mn = fmin(mn, (Mdiag[i] + tau * Kdiag[i]) / A[i]);
+    else
+        for (int i = threadIdx.x; i < n; i += blockDim.x) mn = fmin(mn, Mdiag[i] / A[i]);
+    mn = block_reduce(mn, OpMin(), INFINITY, smem);
+    double lmin = 0.9 * lam_e * fmin(mn, 1.0);
+    if (!(lmin > 0.0) || !(lmin < lmax)) lmin = 0.5 * lmax;   // not an M + dt*(...) system: the check will tell
+    const double rho = (lmax - lmin) / (lmax + lmin);
+    const double xi = 1.0 / rho;
+    const double theta = log(xi + sqrt(xi * xi - 1.0));
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        double w = 1.0;
+        if (k > 0) w = 2.0 * xi * exp(-theta) * (1.0 + exp(-2.0 * k * theta)) / (1.0 + exp(-2.0 * (k + 1) * theta));
+        om[(int64_t)bz * om_bs + k] = w;
+    }
+    if (threadIdx.x == 0) {
+        scale[bz] = 0.5 * (lmin + lmax);
+        KrylovCtl* c = ctl_ + bz;
+        c->flags = 0; c->iters = 0; c->done = 0; c->resid = 0.0; c->bnorm = 0.0;
+        c->alpha = theta;   // asymptotic contraction exp(-theta) per iteration
+        c->omega = lmin;
+    }
+}
+
+// r = b - A x: per-block max |r|, max |b|
+__global__ void k_chs_check(int n, int W, const int32_t* __restrict__ cols, const double* __restrict__ A_, int ashared,
+                            const double* __restrict__ b_, VecRef x_ref, int64_t x_bs, double* __restrict__ part_) {
+    __shared__ double smem[32];
+    const int bz = blockIdx.y;
+    const double* A = A_ + (ashared ? 0 : (int64_t)bz * W * n);
+    const double* b = b_ + (int64_t)bz * n;
+    const double* x = vec_ptr(x_ref) + bz * x_bs;
+    double* part = part_ + (int64_t)bz * 6 * FEMFCT_MAX_PARTIALS;
+    RowRange rr = block_rows(n);
+    double rmax = 0.0, bmax = 0.0;
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        double acc = A[i] * x[i];
+        for (int s = 1; s < W; ++s) {
+            int64_t idx = (int64_t)s * n + i;
+            acc += A[idx] * x[cols[idx]];
+        }
+        const double bi = b[i];
+        const double ri = fabs(bi - acc);
+        rmax = (ri == ri) ? fmax(rmax, ri) : INFINITY;
+        bmax = fmax(bmax, fabs(bi));
+    }
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    bmax = block_reduce(bmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) { KP(part, 4)[blockIdx.x] = rmax; KP(part, 5)[blockIdx.x] = bmax; }
+}
+
+// iters reports the iteration count that would have met tol/10 at the asymptotic rate (the host
+// sizes the next sweep's budget from it); FEMFCT_FLAG_SOLVER_BUDGET when this solve missed tol.
+__global__ void k_chs_finish(const double* __restrict__ part_, int G, KrylovCtl* __restrict__ ctl_, int K, double rel_tol) {
+    __shared__ double smem[32];
+    const int bz = blockIdx.x;
+    const double* part = part_ + (int64_t)bz * 6 * FEMFCT_MAX_PARTIALS;
+    const double rmax = reduce_partials(KP(part, 4), G, OpMax(), 0.0, smem);
+    const double bmax = reduce_partials(KP(part, 5), G, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) {
+        KrylovCtl* c = ctl_ + bz;
+        const double res = bmax > 0.0 ? rmax / bmax : (rmax > 0.0 ? INFINITY : 0.0);
+        c->resid = res;
+        c->bnorm = bmax;
+        c->done = 1;
+        const double theta = c->alpha;
+        double need = K;
+        if (res > 0.0 && res < INFINITY) need = K + log(res / (0.1 * rel_tol)) / theta;
+        else if (res == 0.0) need = 1.0;
+        need = fmin(fmax(need, 1.0), 1.0e6);
+        c->iters = (int)ceil(need);
+        c->flags |= FEMFCT_FLAG_CHEBYSHEV;
+        if (!(res <= rel_tol)) c->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
+    }
+}
+
+}  // namespace
+
+// smallest eigenvalue of diag(Ae)^-1 Ae, Ae = Me + tau*Ke of the right-angled P1 element with legs h
+// (both triangle orientations are congruent): symmetric 3x3, trigonometric formula
+static double element_lambda_min(double h, double tau) {
+    const double T = 0.5 * h * h;
+    const double Me[3][3] = {{T / 6, T / 12, T / 12}, {T / 12, T / 6, T / 12}, {T / 12, T / 12, T / 6}};
+    const double Ke[3][3] = {{1.0, -0.5, -0.5}, {-0.5, 0.5, 0.0}, {-0.5, 0.0, 0.5}};
+    double S[3][3], d[3];
+    for (int i = 0; i < 3; ++i) d[i] = 1.0 / sqrt(Me[i][i] + tau * Ke[i][i]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) S[i][j] = d[i] * (Me[i][j] + tau * Ke[i][j]) * d[j];
+    const double p1 = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+    const double q = (S[0][0] + S[1][1] + S[2][2]) / 3.0;
+    const double p2 = (S[0][0] - q) * (S[0][0] - q) + (S[1][1] - q) * (S[1][1] - q) + (S[2][2] - q) * (S[2][2] - q) + 2.0 * p1;
+    const double p = sqrt(p2 / 6.0);
+    if (!(p > 0.0)) return q;
+    double B[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) B[i][j] = (S[i][j] - (i == j ? q : 0.0)) / p;
+    double r = 0.5 * (B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                      B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]));
+    r = std::min(1.0, std::max(-1.0, r));
+    const double phi = acos(r) / 3.0;
+    return q + 2.0 * p * cos(phi + 2.0 * M_PI / 3.0);
+}
+
+bool femfct_species_cheb(const femfct_ctx* ctx, int kind) {
+    if (ctx->species_solver != 0 || ctx->kind_cheb_off.count(kind)) return false;
+    if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
+    TilePlan tp;
+    return femfct_tile_plan(ctx, &tp, false);
+}
+
+int femfct_cheb_depth(const femfct_ctx* ctx, int32_t batch) {
+    if (femfct_tile4_wanted(ctx, batch)) return 10;
+    TilePlan tp;
+    femfct_tile_plan(ctx, &tp, false);
+    return tp.K;
+}
+
+int femfct_enqueue_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
+                              int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget, double tau) {
+    const int n = ctx->n, W = ctx->W;
+    const int depth = femfct_cheb_depth(ctx, batch);
+    int K = ((budget + depth - 1) / depth) * depth;
+    if (K > ctx->chs_om_cap) K = (ctx->chs_om_cap / depth) * depth;
+    KrylovCtl* ctl = (KrylovCtl*)ctx->d_kry_ctl;
+    hipStream_t st = ctx->stream;
+    femfct_prof_begin(ctx, KC_OTHER);
+    const double lam_e = tau >= 0.0 ? element_lambda_min(ctx->h, tau) : 0.5;
+    hipLaunchKernelGGL(k_chs_setup, dim3(batch), dim3(1024), 0, st, n, W, mat, mat_shared, (const double*)ctx->d_M,
+                       (const double*)ctx->d_Ad, tau, lam_e, 2.2, K, ctx->d_chs_om, ctx->chs_om_cap, ctx->d_chs_scale, ctl);
+    femfct_prof_end(ctx);
+    ChebIO io{};
+    io.mat = mat; io.mat_bs = mat_shared ? 0 : (int64_t)W * n;
+    io.mid_ref = x0; io.mid_bs = x0_bs;
+    io.out_ref = x_out; io.out_bs = out_bs;
+    io.om_dev = ctx->d_chs_om; io.om_bs = ctx->chs_om_cap; io.scale_dev = ctx->d_chs_scale;
+    int rc;
+    // y_out pointer is a placeholder: the last launch writes through io.out_ref
+    if (femfct_tile4_wanted(ctx, batch)) {
+        rc = femfct_enqueue_tile4_cheb(ctx, b, nullptr, nullptr, ctx->d_y0, 1, K, nullptr, 1.0, ctx->d_y0, ctx->d_y2, ctx->d_y1,
+                                       ctx->d_rp, batch, &io);
+    } else {
+        TilePlan tp;
+        femfct_tile_plan(ctx, &tp, false);
+        rc = femfct_enqueue_tile_cheb(ctx, tp, b, nullptr, nullptr, ctx->d_y0, 1, K, nullptr, 1.0, ctx->d_y0, ctx->d_y2,
+                                      ctx->d_y1, ctx->d_rp, batch, &io);
+    }
+    if (rc != FEMFCT_OK) return rc;
+    LaunchGeom g = femfct_geom(ctx, batch);
+    femfct_prof_begin(ctx, KC_OTHER);
+    hipLaunchKernelGGL(k_chs_check, g.grid, g.block, 0, st, n, W, ctx->d_cols, mat, mat_shared, b, x_out, out_bs, ctx->d_kry_part);
+    hipLaunchKernelGGL(k_chs_finish, dim3(batch), dim3(256), 0, st, (const double*)ctx->d_kry_part, (int)g.grid.x, ctl, K,
+                       ctx->kry_tol);
+    femfct_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "Chebyshev solve launch failed: %s", hipGetErrorString(e));
+    return FEMFCT_OK;
+}
+
+// the species solve of a trajectory sweep of the given kind
+int femfct_enqueue_species_solve(femfct_ctx* ctx, int kind, const double* mat, int32_t mat_shared, const double* b,
+                                 VecRef x0, int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget,
+                                 double tau) {
+    if (femfct_species_cheb(ctx, kind))
+        return femfct_enqueue_cheb_solve(ctx, mat, mat_shared, b, x0, x0_bs, x_out, out_bs, batch, budget, tau);
+    return femfct_enqueue_bicgstab(ctx, mat, mat_shared, b, x0, x0_bs, x_out, out_bs, batch, budget);
 }

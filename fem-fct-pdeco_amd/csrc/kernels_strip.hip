@@ -278,7 +278,7 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
     for (int k0 = k_first; k0 <= k_last; k0 += pl.K) {
         int k1 = std::min(k_last + 1, k0 + pl.K);
         CheOmegas om;
-        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas[k - 1];
+        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas ? omegas[k - 1] : 0.0;
         const bool last = (k1 == k_last + 1);
         double* omid = last ? y_out : (which ? bufB0 : bufA0);
         double* oold = last ? nullptr : (which ? bufB1 : bufA1);
@@ -480,10 +480,15 @@ template <int H>
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
             const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
-            CheOmegas om, double md_scale) {
+            CheOmegas om, double md_scale, ChebIO cio) {
     constexpr int W = 7;
     __shared__ double ys[3][TILE_L * TILE_LD];
     const int64_t voff = (int64_t)blockIdx.z * n;
+    if (cio.mat) M = cio.mat + (int64_t)blockIdx.z * cio.mat_bs;
+    if (cio.scale_dev) md_scale = cio.scale_dev[blockIdx.z];
+    const double* omd = cio.om_dev ? cio.om_dev + (int64_t)blockIdx.z * cio.om_bs + cio.k0 : nullptr;
+    if (cio.mid_ref.base) ymid_ = vec_ptr(cio.mid_ref) + (int64_t)blockIdx.z * cio.mid_bs - voff;
+    if (cio.out_ref.base) omid_ = const_cast<double*>(vec_ptr(cio.out_ref)) + (int64_t)blockIdx.z * cio.out_bs - voff;
     const TileGeom g = tile_geom<TILE_L - 2 * H, H>(N);
     double mv[W - 1], md = 1.0, rmd = 1.0, bv = 0.0, ym = 0.0, yo = 0.0;
 #pragma unroll
@@ -511,7 +516,8 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
             for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
             const double z = (bv - acc) * rmd;
             const double yov = ys[io][g.self];
-            yn = om.w[k] * (z + ymv - yov) + yov;
+            const double wk = omd ? omd[k] : om.w[k];
+            yn = wk * (z + ymv - yov) + yov;
         }
         ys[in_][g.self] = yn;
         __syncthreads();
@@ -708,20 +714,28 @@ int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double
 
 int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
-                             double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch) {
+                             double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch,
+                             const ChebIO* io_in) {
+    ChebIO io0{};
+    if (io_in) io0 = *io_in;
+    io0.mid_ref = make_ref(nullptr); io0.mid_bs = 0; io0.out_ref = make_ref(nullptr); io0.out_bs = 0;
     const double* mid = in_mid;
     const double* old = in_old;
     int which = 0;
     for (int k0 = k_first; k0 <= k_last; k0 += pl.K) {
         int k1 = std::min(k_last + 1, k0 + pl.K);
         CheOmegas om;
-        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas[k - 1];
+        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas ? omegas[k - 1] : 0.0;
         const bool last = (k1 == k_last + 1);
         double* omid = last ? y_out : (which ? bufB0 : bufA0);
         double* oold = last ? nullptr : (which ? bufB1 : bufA1);
         femfct_prof_begin(ctx, KC_CHEB);
+        ChebIO io = io0;
+        io.k0 = k0 - 1;
+        if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
+        if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
 #define TC(HH) hipLaunchKernelGGL((k_tile_cheb<HH>), dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, \
-                                  ctx->N, ctx->d_M, b, mid, old, omid, oold, k1 - k0, om, md_scale)
+                                  ctx->N, ctx->d_M, b, mid, old, omid, oold, k1 - k0, om, md_scale, io)
         if (pl.H == 8) TC(8); else if (pl.H == 9) TC(9); else TC(10);
 #undef TC
         femfct_prof_end(ctx);
@@ -842,7 +856,7 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, VecRef rhs, 
     tp.H = H; tp.K = H; tp.tiles = t;
     // remaining iterations K+2 .. iters; inputs (mid, old) = (y0, y2); scratch pair (y1, rp) then (y0, y2)
     return femfct_enqueue_tile_cheb(ctx, tp, ctx->d_rdu, ctx->d_y0, ctx->d_y2, ctx->d_du, K + 2, iters, omegas, md_scale,
-                                    ctx->d_y1, ctx->d_rp, ctx->d_y0, ctx->d_y2, batch);
+                                    ctx->d_y1, ctx->d_rp, ctx->d_y0, ctx->d_y2, batch, nullptr);
 }
 
 // ===========================================================================================
@@ -985,9 +999,14 @@ k_tile4_jacobi(int n, int N, const double* __restrict__ L_, const double* __rest
 __global__ void __launch_bounds__(STRIP_T)
 k_tile4_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
              const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
-             CheOmegas om, double md_scale) {
+             CheOmegas om, double md_scale, ChebIO cio) {
     constexpr int W = 7;
     extern __shared__ double lds[];
+    if (cio.mat) M = cio.mat + (int64_t)blockIdx.z * cio.mat_bs;
+    if (cio.scale_dev) md_scale = cio.scale_dev[blockIdx.z];
+    const double* omd = cio.om_dev ? cio.om_dev + (int64_t)blockIdx.z * cio.om_bs + cio.k0 : nullptr;
+    if (cio.mid_ref.base) ymid_ = vec_ptr(cio.mid_ref) + (int64_t)blockIdx.z * cio.mid_bs - (int64_t)blockIdx.z * n;
+    if (cio.out_ref.base) omid_ = const_cast<double*>(vec_ptr(cio.out_ref)) + (int64_t)blockIdx.z * cio.out_bs - (int64_t)blockIdx.z * n;
     double* y_old = lds;
     double* y_mid = lds + T4_BUF;
     double* y_new = lds + 2 * T4_BUF;
@@ -1024,7 +1043,8 @@ k_tile4_cheb(int n, int N, const double* __restrict__ M, const double* __restric
                 for (int s = 0; s < W - 1; ++s) acc += mv[q][s] * y_mid[g[q].self + t4_off(s)];
                 const double z = (bv[q] - acc) * rmd[q];
                 const double yov = y_old[g[q].self];
-                yn = om.w[k] * (z + ymv - yov) + yov;
+                const double wk = omd ? omd[k] : om.w[k];
+                yn = wk * (z + ymv - yov) + yov;
             }
             if (g[q].inside) y_new[g[q].self] = yn;
         }
@@ -1080,7 +1100,10 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
 
 int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
-                              double* bufB0, double* bufB1, int32_t batch) {
+                              double* bufB0, double* bufB1, int32_t batch, const ChebIO* io_in) {
+    ChebIO io0{};
+    if (io_in) io0 = *io_in;
+    io0.mid_ref = make_ref(nullptr); io0.mid_bs = 0; io0.out_ref = make_ref(nullptr); io0.out_bs = 0;
     const int t = femfct_tile4_tiles(ctx);
     const size_t lds = (size_t)3 * T4_BUF * 8;
     const double* mid = in_mid;
@@ -1089,13 +1112,17 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
     for (int k0 = k_first; k0 <= k_last; k0 += T4_H) {
         int k1 = std::min(k_last + 1, k0 + T4_H);
         CheOmegas om;
-        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas[k - 1];
+        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas ? omegas[k - 1] : 0.0;
         const bool last = (k1 == k_last + 1);
         double* omid = last ? y_out : (which ? bufB0 : bufA0);
         double* oold = last ? nullptr : (which ? bufB1 : bufA1);
+        ChebIO io = io0;
+        io.k0 = k0 - 1;
+        if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
+        if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
         hipLaunchKernelGGL(k_tile4_cheb, dim3(t, t, batch), dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
-                           old, omid, oold, k1 - k0, om, md_scale);
+                           old, omid, oold, k1 - k0, om, md_scale, io);
         femfct_prof_end(ctx);
         mid = omid;
         old = oold;

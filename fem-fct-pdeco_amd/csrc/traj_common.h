@@ -48,10 +48,13 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
     // budgets are remembered per kind of sweep: the forward and the adjoint operator of a problem
     // need different sweep counts, and a shared budget would make them evict each other
     if (!ctx->kind_budget.count(kind)) ctx->kind_budget[kind] = 48;
-    if (!ctx->kind_kbudget.count(kind)) ctx->kind_kbudget[kind] = 40;
     for (;;) {
+        // species solves: Chebyshev (structured mesh) and BiCGStab keep separate iteration budgets
+        const bool cheb = krylov && femfct_species_cheb(ctx, kind);
+        const int kkey = cheb ? kind : kind + 1000;
+        if (!ctx->kind_kbudget.count(kkey)) ctx->kind_kbudget[kkey] = 40;
         const int budget = femfct_round_budget(ctx, ctx->kind_budget[kind]);
-        const int kbudget = femfct_round_kry_budget(ctx, ctx->kind_kbudget[kind]);
+        const int kbudget = femfct_round_kry_budget(ctx, ctx->kind_kbudget[kkey]);
         int rc = begin();
         if (rc != FEMFCT_OK) return rc;
         int32_t init[2] = {level0, 0};
@@ -98,7 +101,10 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
                     kbudget, worst, kworst, (int)short_budget, (int)kshort);
         if (!short_budget && !kshort) {
             ctx->kind_budget[kind] = femfct_next_budget(ctx, worst, coarse);
-            if (krylov) ctx->kind_kbudget[kind] = std::min(ctx->kry_max_iters, std::max(8, kworst + kworst / 4 + 2));
+            // (Chebyshev reports the count that meets tol/10 at its asymptotic rate: no extra margin)
+            if (krylov)
+                ctx->kind_kbudget[kkey] = std::min(ctx->kry_max_iters, cheb ? std::max(8, kworst + 1)
+                                                                             : std::max(8, kworst + kworst / 4 + 2));
             return FEMFCT_OK;
         }
         if (short_budget) {
@@ -108,12 +114,16 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
                                    budget, ctx->rel_tol);
             ctx->kind_budget[kind] = femfct_grow_budget(ctx, budget);
         }
-        if (kshort) {
+        if (kshort && cheb) {
+            // not contracting (complex spectrum outside the assumed interval) or out of budget: BiCGStab
+            if (!(kworst_res < 10.0) || kbudget >= ctx->kry_max_iters) ctx->kind_cheb_off.insert(kind);
+            else ctx->kind_kbudget[kkey] = std::min(ctx->kry_max_iters, std::max(kbudget + 10, kworst + kworst / 10 + 5));
+        } else if (kshort) {
             if (kbudget >= ctx->kry_max_iters)
                 return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
                                    "BiCGStab: residual %.3e after %d iterations (tol %.1e)", kworst_res, kbudget,
                                    ctx->kry_tol);
-            ctx->kind_kbudget[kind] = std::min(ctx->kry_max_iters, kbudget * 2);
+            ctx->kind_kbudget[kkey] = std::min(ctx->kry_max_iters, kbudget * 2);
         }
     }
 }

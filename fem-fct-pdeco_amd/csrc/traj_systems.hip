@@ -76,6 +76,13 @@ int femfct_set_krylov(femfct_ctx* ctx, double rel_tol, int32_t max_iters) {
     return FEMFCT_OK;
 }
 
+int femfct_set_species_solver(femfct_ctx* ctx, int32_t mode) {
+    ARG_TRY(ctx, ctx && (mode == FEMFCT_SPECIES_AUTO || mode == FEMFCT_SPECIES_BICGSTAB), "unknown species solver");
+    ctx->species_solver = mode;
+    ctx->kind_cheb_off.clear();
+    return FEMFCT_OK;
+}
+
 // spsolve(Mat, b) replacement for the non-FCT implicit solves (helpers.py:596,686,1342,1538):
 // Jacobi-preconditioned BiCGStab, x0 = initial guess, synchronises, FEMFCT_ERR_NOT_CONVERGED on failure.
 int femfct_bicgstab(femfct_ctx* ctx, const double* mat_ell, int32_t mat_shared, const double* b_dev,
@@ -210,7 +217,8 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
         auto key = KEY((uint64_t)12, key_bits(Aw_ell), key_bits(c_level), key_bits(u_traj), key_bits(v_traj),
                        key_bits(num_steps), key_bits(dt), key_bits(Du), key_bits(Dv), key_bits(c_b), key_bits(gam),
                        key_bits(om1), key_bits(om2), key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget),
-                       key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol));
+                       key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
+                       key_bits((int32_t)femfct_species_cheb(ctx, 12)));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             LoadSpec l1;  // (gamma/r*c + gamma*u_n^2*v_n)*v*dx  (helpers.py:584-585)
             l1.s1 = 1.0; l1.k1 = gam / rescaling; l1.p1 = make_ref(c_level); l1.p1_bs = n;
@@ -227,7 +235,7 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
             LoadSpec l2;  // M@v_n + dt*assemble(gamma*c_b*v*dx)  (helpers.py:594,596)
             l2.s0 = 1.0; l2.mx = L(v_traj, 0); l2.mx_bs = ts; l2.s1 = dt; l2.k0 = gam * c_b;
             femfct_enqueue_load(ctx, l2, ctx->d_trRhs2, batch);
-            r = femfct_enqueue_bicgstab(ctx, ctx->d_trMat, 0, ctx->d_trRhs2, L(v_traj, 0), ts, L(v_traj, 1), ts, batch, kbudget);
+            r = femfct_enqueue_species_solve(ctx, 12, ctx->d_trMat, 0, ctx->d_trRhs2, L(v_traj, 0), ts, L(v_traj, 1), ts, batch, kbudget, dt * Dv);
             if (r != FEMFCT_OK) return r;
             return femfct_enqueue_step_end(ctx, 1, batch, true);
         });
@@ -260,7 +268,8 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
         auto key = KEY((uint64_t)13, key_bits(AwT_ell), key_bits(u_traj), key_bits(v_traj), key_bits(uhat_T),
                        key_bits(vhat_T), key_bits(p_traj), key_bits(q_traj), key_bits(num_steps), key_bits(dt),
                        key_bits(Du), key_bits(Dv), key_bits(gam), key_bits(om1), key_bits(om2), key_bits(batch),
-                       key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol));
+                       key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
+                       key_bits((int32_t)femfct_species_cheb(ctx, 13)));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // q first (helpers.py:683-686): Mat_q = M + dt*(Dv*Ad - omega2*A' + gamma*M_u2(u_n))
             WMassSpec wq;
@@ -271,7 +280,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
             lq.s0 = 1.0; lq.mx = L(q_traj, 1); lq.mx_bs = ts; lq.s1 = dt; lq.k2 = gam;
             lq.q1 = L(p_traj, 1); lq.q2 = L(u_traj, 0); lq.q3 = L(u_traj, 0); lq.q1_bs = lq.q2_bs = lq.q3_bs = ts;
             femfct_enqueue_load(ctx, lq, ctx->d_trRhs2, batch);
-            int r = femfct_enqueue_bicgstab(ctx, ctx->d_trMat, 0, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget);
+            int r = femfct_enqueue_species_solve(ctx, 13, ctx->d_trMat, 0, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget, dt * Dv);
             if (r != FEMFCT_OK) return r;
             // then p by FCT (helpers.py:690-697): N = gamma*M - 2*gamma*M_uv, rhs = -2*gamma*u_n*v_n*q_n
             WMassSpec wn_;
@@ -312,13 +321,14 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
         auto key = KEY((uint64_t)14, key_bits(c_level), key_bits(u_traj), key_bits(v_traj), key_bits(num_steps),
                        key_bits(dt), key_bits(delta), key_bits(Dm), key_bits(Df), key_bits(chi), key_bits(eta),
                        key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget), key_bits((int32_t)kbudget),
-                       key_bits(ctx->rel_tol), key_bits(ctx->kry_tol));
+                       key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
+                       key_bits((int32_t)femfct_species_cheb(ctx, 14)));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             LoadSpec l2;  // assemble(v_n*v*dx + dt*c*u_n/r*v*dx)  (helpers.py:1339-1340)
             l2.s0 = 1.0; l2.mx = L(v_traj, 0); l2.mx_bs = ts; l2.s1 = dt / rescaling; l2.k2 = 1.0;
             l2.q1 = make_ref(c_level); l2.q1_bs = n; l2.q2 = L(u_traj, 0); l2.q2_bs = ts;
             femfct_enqueue_load(ctx, l2, ctx->d_trRhs2, batch);
-            int r = femfct_enqueue_bicgstab(ctx, ctx->d_trBase, 1, ctx->d_trRhs2, L(v_traj, 0), ts, L(v_traj, 1), ts, batch, kbudget);
+            int r = femfct_enqueue_species_solve(ctx, 14, ctx->d_trBase, 1, ctx->d_trRhs2, L(v_traj, 0), ts, L(v_traj, 1), ts, batch, kbudget, dt * Df);
             if (r != FEMFCT_OK) return r;
             // A_var1 = Dm*Ad - chi*Aa(u_n, v_{n+1})  (helpers.py:1350-1352)
             femfct_enqueue_chtxs_matrix(ctx, 0, L(u_traj, 0), ts, L(v_traj, 1), ts, Dm, chi, eta, ctx->d_trA, batch);
@@ -361,7 +371,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
                        key_bits(q_traj), key_bits(c_traj), key_bits(num_steps), key_bits(dt), key_bits(delta),
                        key_bits(Dm), key_bits(Df), key_bits(chi), key_bits(eta), key_bits(rescaling), key_bits(alltime),
                        key_bits(batch), key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol),
-                       key_bits(ctx->kry_tol));
+                       key_bits(ctx->kry_tol), key_bits((int32_t)femfct_species_cheb(ctx, 15)));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // Mat_p = Dm*Ad - chi*Aa'(u_n, v_n)  (helpers.py:1499-1503)
             femfct_enqueue_chtxs_matrix(ctx, 1, L(u_traj, 0), ts, L(v_traj, 0), ts, Dm, chi, eta, ctx->d_trA, batch);
@@ -379,7 +389,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
             LoadSpec lq;  // M@q_{n+1} + dt*rhs_q  (helpers.py:1538)
             lq.s0 = 1.0; lq.mx = L(q_traj, 1); lq.mx_bs = ts; lq.s2 = dt; lq.da = make_ref(ctx->d_trTmp); lq.da_bs = n;
             femfct_enqueue_load(ctx, lq, ctx->d_trRhs2, batch);
-            r = femfct_enqueue_bicgstab(ctx, ctx->d_trBase, 1, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget);
+            r = femfct_enqueue_species_solve(ctx, 15, ctx->d_trBase, 1, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget, dt * Df);
             if (r != FEMFCT_OK) return r;
             return femfct_enqueue_step_end(ctx, -1, batch, true);
         });

@@ -318,6 +318,10 @@ class Context:
     def set_krylov(self, rel_tol=1e-13, max_iters=2000):
         check(self.handle, lib.femfct_set_krylov(self.handle, float(rel_tol), int(max_iters)))
 
+    def set_species_solver(self, mode="auto"):
+        """'auto': tile-fused Chebyshev for the non-FCT solves of the sweeps where it applies; 'bicgstab'."""
+        check(self.handle, lib.femfct_set_species_solver(self.handle, {"auto": 0, "bicgstab": 1}[mode]))
+
     def bicgstab(self, mat_ell, b, x0, x, batch=1, mat_shared=False):
         arr = (StepInfo * batch)()
         check(self.handle, lib.femfct_bicgstab(self.handle, dptr(mat_ell), int(bool(mat_shared)), dptr(b), dptr(x0),

@@ -119,7 +119,10 @@ def _system(V: SquareMeshP1) -> PDESystems:
             for old in _cache.values():
                 old.close()
             _cache.clear()
-        s = PDESystems(V)
+        # the device works in vertex (lexicographic) order, where the index-free tile kernels and the
+        # Chebyshev species solve apply; _Bufs permutes FEniCS-ordered host vectors at the boundary
+        s = PDESystems(V, order=_lib.ORDER_VERTEX)
+        s.v2d = np.asarray(V.vertex_to_dof, dtype=np.int64)
         _cache[V.key()] = s
     return s
 
@@ -131,13 +134,23 @@ def _frozen_control(control, control_fun, nodes):
 
 
 class _Bufs:
-    def __init__(self, ctx):
-        self.ctx, self.items = ctx, []
+    """Host (FEniCS DoF order, level-major) <-> device (vertex order) staging of one call."""
+
+    def __init__(self, S):
+        self.ctx, self.items, self.v2d, self.n = S.ctx, [], S.v2d, S.n
 
     def up(self, x):
-        d = self.ctx.array(np.asarray(x, dtype=np.float64).ravel())
+        x = np.asarray(x, dtype=np.float64).ravel()
+        d = self.ctx.array(np.ascontiguousarray(x.reshape(-1, self.n)[:, self.v2d]).ravel())
         self.items.append(d)
         return d
+
+    def down(self, d, out):
+        """device vector(s) -> ``out`` (in place), back in FEniCS DoF order"""
+        tmp = np.empty((d.count // self.n, self.n))
+        tmp[:, self.v2d] = d.download().reshape(-1, self.n)
+        out[...] = tmp.reshape(out.shape)
+        return out
 
     def zeros(self, count):
         d = self.ctx.zeros(count)
@@ -159,11 +172,11 @@ def solve_nonlinear_equation(control, var1, var2, V, nodes, num_steps, dt, dof_n
     eps, _, wind = get_nonlinear_eqns_params()
     Aw, _ = S.convection(wind, "nonlinear")
     var1[nodes:] = np.zeros(num_steps * nodes)
-    B = _Bufs(S.ctx)
+    B = _Bufs(S)
     try:
         u = B.up(var1)
         S.ctx.nonlinear_forward(Aw, B.up(_frozen_control(control, control_fun, nodes)), u, num_steps, dt, eps)
-        u.download(var1)
+        B.down(u, var1)
     finally:
         B.free()
     return var1, None
@@ -174,11 +187,11 @@ def solve_adjoint_nonlinear_equation(uk, uhat_T, pk, T, V, nodes, num_steps, dt,
     S = _system(V)
     eps, _, wind = get_nonlinear_eqns_params()
     Aw, _ = S.convection(wind, "nonlinear")
-    B = _Bufs(S.ctx)
+    B = _Bufs(S)
     try:
         p = B.up(pk)
         S.ctx.nonlinear_adjoint(Aw, B.up(uk), B.up(uhat_T), p, num_steps, dt, eps)
-        p.download(pk)
+        B.down(p, pk)
     finally:
         B.free()
     return pk
@@ -198,12 +211,12 @@ def solve_schnak_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighb
     Aw, _ = S.convection(wind, "schnak")
     var1[nodes:] = np.zeros(num_steps * nodes)
     var2[nodes:] = np.zeros(num_steps * nodes)
-    B = _Bufs(S.ctx)
+    B = _Bufs(S)
     try:
         u, v = B.up(var1), B.up(var2)
         S.ctx.schnak_forward(Aw, B.up(_frozen_control(control, control_fun, nodes)), u, v, num_steps, dt, par, rescaling)
-        u.download(var1)
-        v.download(var2)
+        B.down(u, var1)
+        B.down(v, var2)
     finally:
         B.free()
     return var1, var2
@@ -214,12 +227,12 @@ def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, V, nodes, num
     S = _system(V)
     par, wind = _schnak_par()
     _, AwT = S.convection(wind, "schnak")
-    B = _Bufs(S.ctx)
+    B = _Bufs(S)
     try:
         p, q = B.up(pk), B.up(qk)
         S.ctx.schnak_adjoint(AwT, B.up(uk), B.up(vk), B.up(uhat_T), B.up(vhat_T), p, q, num_steps, dt, par)
-        p.download(pk)
-        q.download(qk)
+        B.down(p, pk)
+        B.down(q, qk)
     finally:
         B.free()
     return pk, qk
@@ -237,7 +250,7 @@ def solve_chtxs_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighbo
     """helpers.py:1250-1385."""
     S = _system(V)
     par = _chtxs_par()
-    B = _Bufs(S.ctx)
+    B = _Bufs(S)
     try:
         if generation_mode:
             if len(var1) != nodes or len(var2) != nodes or len(control) != nodes:
@@ -250,7 +263,7 @@ def solve_chtxs_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighbo
             u, v = B.up(u0), B.up(v0)
             S.ctx.chtxs_forward(B.up(c_level), u, v, num_steps, dt, par, rescaling)
             if output_dir is not None:
-                uu, vv = u.download(), v.download()
+                uu, vv = B.down(u, np.empty(tl)), B.down(v, np.empty(tl))
                 t = 0
                 for i in range(1, num_steps + 1):
                     t += dt
@@ -262,8 +275,8 @@ def solve_chtxs_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighbo
         var2[nodes:] = np.zeros(num_steps * nodes)
         u, v = B.up(var1), B.up(var2)
         S.ctx.chtxs_forward(B.up(_frozen_control(control, control_fun, nodes)), u, v, num_steps, dt, par, rescaling)
-        u.download(var1)
-        v.download(var2)
+        B.down(u, var1)
+        B.down(v, var2)
     finally:
         B.free()
     return var1, var2
@@ -277,13 +290,13 @@ def solve_adjoint_chtxs_system(uk, vk, uhat, vhat, pk, qk, control, T, V, nodes,
     if optim not in valid_options:
         raise ValueError(f"Invalid value for 'optim': '{optim}'. Must be one of {valid_options}.")
     S = _system(V)
-    B = _Bufs(S.ctx)
+    B = _Bufs(S)
     try:
         p, q = B.up(pk), B.up(qk)
         S.ctx.chtxs_adjoint(B.up(uk), B.up(vk), B.up(uhat), B.up(vhat), p, q, B.up(control), num_steps, dt,
                             _chtxs_par(), rescaling, optim == "alltime")
-        p.download(pk)
-        q.download(qk)
+        B.down(p, pk)
+        B.down(q, qk)
     finally:
         B.free()
     return pk, qk

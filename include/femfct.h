@@ -55,6 +55,8 @@ typedef struct femfct_ctx femfct_ctx;
                                          the "3: False" diagnostic of helpers.py:1796-1799 */
 #define FEMFCT_FLAG_SOLVER_BUDGET  2  /* sweep/iteration budget exhausted before tolerance */
 #define FEMFCT_FLAG_COARSE_ITERS   4  /* solver_iters is an upper bound (whole fused launches), not the exact count */
+#define FEMFCT_FLAG_CHEBYSHEV      8  /* species solve done by the Chebyshev iteration; solver_iters is the count that
+                                         meets tolerance/10 at its asymptotic rate (the next sweep's budget) */
 
 /* DoF numbering of the structured mesh */
 #define FEMFCT_ORDER_VERTEX 0         /* iy*N+ix (dolfin vertex order) */
@@ -221,8 +223,14 @@ int femfct_ell_transpose(femfct_ctx* ctx, const double* in_ell, double* out_ell)
 /* out = alpha*a + beta*b over count doubles (b may be NULL): Du*Ad - omega1*A etc. (helpers.py:583) */
 int femfct_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a_dev, double beta,
                  const double* b_dev, double* out_dev);
-/* tolerance / iteration cap of the BiCGStab used for the non-FCT implicit solves */
+/* tolerance / iteration cap of the iterative solver used for the non-FCT implicit solves */
 int femfct_set_krylov(femfct_ctx* ctx, double rel_tol, int32_t max_iters);
+/* solver of those solves inside the trajectory sweeps: FEMFCT_SPECIES_AUTO = tile-fused Chebyshev
+ * iteration on the structured vertex-order mesh (falls back to BiCGStab when it does not contract),
+ * FEMFCT_SPECIES_BICGSTAB = always BiCGStab.  Both meet the same residual tolerance. */
+#define FEMFCT_SPECIES_AUTO 0
+#define FEMFCT_SPECIES_BICGSTAB 1
+int femfct_set_species_solver(femfct_ctx* ctx, int32_t mode);
 /* spsolve(Mat, b) (helpers.py:596,686,1342,1538): Jacobi-preconditioned BiCGStab from the initial guess
  * x0; mat_shared != 0: one matrix for the whole batch.  Synchronises. */
 int femfct_bicgstab(femfct_ctx* ctx, const double* mat_ell, int32_t mat_shared, const double* b_dev,

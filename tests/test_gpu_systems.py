@@ -150,3 +150,47 @@ def test_chemotaxis_forward_adjoint_vs_oracle(hp, optim):
     assert rel(pg, po) < 1e-8 and rel(qg, qo) < 1e-8
     with pytest.raises(ValueError):
         hp.solve_adjoint_chtxs_system(ug, vg, uhat, vhat, pg, qg, ctrl, Nt * dt, V, n, Nt, dt, None, "sometime")
+
+
+def test_species_chebyshev_matches_bicgstab(hp):
+    """The tile-fused Chebyshev species solve (vertex order) and BiCGStab meet the same tolerance:
+    identical Schnakenberg / chemotaxis trajectories to solver accuracy; the flag tells which ran."""
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 12, 5e-4
+    rng = np.random.default_rng(11)
+    S = systems.PDESystems(V, order=hp.ORDER_VERTEX)
+    ctx = S.ctx
+    try:
+        par, wind = systems._schnak_par()
+        Aw, AwT = S.convection(wind, "schnak")
+        u0, v0 = hp.schnak_sys_IC(0, 1, 0.025, n, np.arange(n))
+        c = ctx.array(0.1 + 0.01 * rng.random(n))
+        cpar = systems._chtxs_par()
+        cc = ctx.array(20 * rng.random(n))
+        uc0 = 1.5 + 0.1 * (0.5 - rng.random(n))
+        uh, vh = rng.random(n), rng.random(n)
+        res = {}
+        for mode in ("auto", "bicgstab"):
+            ctx.set_species_solver(mode)
+            def traj(x0):
+                a = np.zeros((Nt + 1) * n)
+                a[:n] = x0
+                return ctx.array(a)
+            u, v, p, q = traj(u0), traj(v0), traj(0 * u0), traj(0 * u0)
+            ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0)
+            kf = ctx.traj_krylov_info(Nt)
+            ctx.schnak_adjoint(AwT, u, v, ctx.array(uh), ctx.array(vh), p, q, Nt, dt, par)
+            ka = ctx.traj_krylov_info(Nt)
+            uc, vc = traj(uc0), traj(uc0)
+            ctx.chtxs_forward(cc, uc, vc, Nt, dt, cpar, 0.1)
+            kc = ctx.traj_krylov_info(Nt)
+            res[mode] = [x.download() for x in (u, v, p, q, uc, vc)]
+            for k in (kf, ka, kc):
+                assert np.all((k["flags"] & hp.FLAG_SOLVER_BUDGET) == 0)
+                assert np.all(((k["flags"] & hp.FLAG_CHEBYSHEV) != 0) == (mode == "auto"))
+                assert k["solver_resid"].max() <= 1e-13
+        for a, b in zip(res["auto"], res["bicgstab"]):
+            assert rel(a, b) < 1e-10
+    finally:
+        S.close()

@@ -46,21 +46,21 @@ Aw, AwT = S.convection(wind, "schnak")
 u, v, p, q = traj(u0s), traj(v0s), traj(np.zeros(n)), traj(np.zeros(n))
 t = timeit(lambda: ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0))
 kinfo = ctx.traj_krylov_info(Nt)
-print(f"Schnakenberg forward : {Nt / t:8.0f} steps/s  (BiCGStab iters max {kinfo['solver_iters'].max()}, jacobi sweeps max {ctx.traj_info(Nt)['solver_iters'].max()})")
+print(f"Schnakenberg forward : {Nt / t:8.0f} steps/s  (species-solve iters max {kinfo['solver_iters'].max()}, jacobi sweeps max {ctx.traj_info(Nt)['solver_iters'].max()})")
 uh, vh = ctx.array(rng.random(n)), ctx.array(rng.random(n))
 t = timeit(lambda: ctx.schnak_adjoint(AwT, u, v, uh, vh, p, q, Nt, dt, par))
-print(f"Schnakenberg adjoint : {Nt / t:8.0f} steps/s  (BiCGStab iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
+print(f"Schnakenberg adjoint : {Nt / t:8.0f} steps/s  (species-solve iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
 
 u0c = 1.5 + 0.1 * (0.5 - rng.random(n))
 u, v, p, q = traj(u0c), traj(u0c), traj(np.zeros(n)), traj(np.zeros(n))
 cpar = systems._chtxs_par()
 cc = ctx.array(20 * rng.random(n))
 t = timeit(lambda: ctx.chtxs_forward(cc, u, v, Nt, dt, cpar, 0.1))
-print(f"chemotaxis forward   : {Nt / t:8.0f} steps/s  (BiCGStab iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
+print(f"chemotaxis forward   : {Nt / t:8.0f} steps/s  (species-solve iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
 ct = ctx.array(20 * rng.random(tl))
 uh, vh = ctx.array(rng.random(tl)), ctx.array(rng.random(tl))
 t = timeit(lambda: ctx.chtxs_adjoint(u, v, uh, vh, p, q, ct, Nt, dt, cpar, 0.1, True))
-print(f"chemotaxis adjoint   : {Nt / t:8.0f} steps/s  (BiCGStab iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
+print(f"chemotaxis adjoint   : {Nt / t:8.0f} steps/s  (species-solve iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
 
 eps, _, nwind = hp.get_nonlinear_eqns_params()
 Awn, _ = S.convection(nwind, "nonlinear")
