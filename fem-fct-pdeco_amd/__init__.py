@@ -24,6 +24,7 @@ from .systems import (  # noqa: F401
     get_schnak_sys_params, get_nonlinear_eqns_params, get_chtxs_sys_params,
     schnak_sys_IC, nonlinear_equation_IC, chtxs_sys_IC, armijo_line_search_ref, assemble_mass)
 from .data_io import import_data_final, extract_data, save_trajectory  # noqa: F401
-from . import fct_helpers, systems, solvers, sweep, data_io  # noqa: F401
+from .pdeco import projected_gradient_descent, SystemPDECO  # noqa: F401
+from . import fct_helpers, systems, solvers, sweep, data_io, pdeco  # noqa: F401
 
 __version__ = "0.1.0"

@@ -102,6 +102,7 @@ SIGNATURES = {
     "femfct_solidbody_forward": (C.c_int, [_p, _p, _p, _i, _p, _i, _d, _d, _d, _d, _d, _i]),
     "femfct_solidbody_adjoint": (C.c_int, [_p, _p, _p, _i, _p, _p, _p, _i, _d, _d, _d, _d, _d, _i, _i]),
     "femfct_traj_info": (C.c_int, [_p, C.POINTER(StepInfo), _i, _i]),
+    "femfct_descent_pointwise": (C.c_int, [_p, C.c_int64, _d, _p, _d, _p, _p, _d, _p]),
     "femfct_ell_transpose": (C.c_int, [_p, _p, _p]),
     "femfct_axpby": (C.c_int, [_p, C.c_int64, _d, _p, _d, _p, _p]),
     "femfct_set_krylov": (C.c_int, [_p, _d, _i]),

@@ -60,6 +60,22 @@ __global__ void k_clip_axpy(int64_t count, const double* __restrict__ c, double 
     for (; k < count; k += stride) out[k] = fmin(fmax(c[k] + s * d[k], lo), hi);
 }
 
+// d = -(beta*c - t),  t = x*y/divisor (y given) or scale*x: the pointwise gradient expressions of the
+// refactored drivers, evaluated in the reference's operation order (no contraction: -ffp-contract=off)
+//   nonlinear_FCT_PDECO_refactored.py:148   dk = -(beta*ck - pk)
+//   Schnak_FCT_PDECO_refactored.py:167      dk = -(beta*ck - gamma/rescaling*pk)
+//   chemotaxis_FCT_PDECO_AT_refactored.py:158   dk = -(beta*ck - qk*uk/rescaling)
+__global__ void k_descent_pointwise(int64_t count, double beta, const double* __restrict__ c, double scale,
+                                    const double* __restrict__ x, const double* __restrict__ y, double divisor,
+                                    double* __restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < count; k += stride) {
+        const double t = y ? (x[k] * y[k]) / divisor : scale * x[k];
+        out[k] = -(beta * c[k] - t);
+    }
+}
+
 int ensure_scratch(femfct_ctx* ctx, size_t doubles) {
     if (doubles <= ctx->scratch_count) return FEMFCT_OK;
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
@@ -150,6 +166,18 @@ int femfct_cost_functional(femfct_ctx* ctx, const double* var1, const double* va
     enqueue_norm(ctx, control, nullptr, n, n, levels, 1, 0.5 * beta * dt, 1, batch, J, 0);
     HIP_TRY(ctx, hipMemcpyAsync(J_host, J, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FEMFCT_OK;
+}
+
+int femfct_descent_pointwise(femfct_ctx* ctx, int64_t count, double beta, const double* c_dev, double scale,
+                             const double* x_dev, const double* y_dev, double divisor, double* out_dev) {
+    ARG_TRY(ctx, ctx && c_dev && x_dev && out_dev && count >= 0 && divisor != 0.0, "bad argument");
+    int bs = 256;
+    int64_t g = (count + bs - 1) / bs;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_descent_pointwise, dim3((unsigned)g), dim3(bs), 0, ctx->stream, count, beta, c_dev, scale, x_dev,
+                       y_dev, divisor, out_dev);
     return FEMFCT_OK;
 }
 

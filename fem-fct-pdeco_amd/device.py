@@ -306,6 +306,11 @@ class Context:
                                                       float(c_upper), dptr(out), int(count)))
 
     # -- non-FCT species / PDE systems ---------------------------------------------------
+    def descent_pointwise(self, count, beta, c, x, out, y=None, scale=1.0, divisor=1.0):
+        """out = -(beta*c - t), t = x*y/divisor (y given) or scale*x"""
+        check(self.handle, lib.femfct_descent_pointwise(self.handle, int(count), float(beta), dptr(c), float(scale), dptr(x),
+                                                       dptr(y), float(divisor), dptr(out)))
+
     def ell_transpose(self, src, out=None) -> DeviceArray:
         if out is None:
             out = self.empty(self.W * self.n)

@@ -215,6 +215,12 @@ int femfct_cost_functional(femfct_ctx* ctx, const double* var1, const double* va
 int femfct_project_control(femfct_ctx* ctx, const double* c_dev, double s, const double* d_dev,
                            double c_lower, double c_upper, double* out_dev, int64_t count);
 
+/* descent direction of the pointwise-gradient problems, d = -(beta*c - t) with t = x*y/divisor (y given)
+ * or t = scale*x (y NULL): nonlinear_FCT_PDECO_refactored.py:148, Schnak_FCT_PDECO_refactored.py:167,
+ * chemotaxis_FCT_PDECO_AT_refactored.py:158 (same floating-point operation order) */
+int femfct_descent_pointwise(femfct_ctx* ctx, int64_t count, double beta, const double* c_dev, double scale,
+                             const double* x_dev, const double* y_dev, double divisor, double* out_dev);
+
 /* ------------------------------------------------ non-FCT species and the three PDE systems */
 
 /* out = in^T on the registered pattern: assemble_sparse(dot(wind,grad(u))*w*dx) (helpers.py:681) is the

@@ -1,0 +1,81 @@
+"""GPU parity of the device-resident projected-gradient loops (fem-fct-pdeco_amd/pdeco.py) against
+the CPU restatement of the refactored drivers' loop (oracle/pdeco.py) on small instances of the three
+PDE-constrained problems: cost histories, Armijo trial counts, final control, states and adjoints."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    mod = importlib.import_module("fem-fct-pdeco_amd")
+    mod.fct_helpers.VERBOSE = False
+    return mod
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _setup(hp, problem, nc, Nt, dt):
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    from oracle import traj as otraj
+    mesh = SquareMesh(0.0, 1.0, nc)
+    asm = P1Assembler(mesh)
+    V = hp.SquareMeshP1(0.0, 1.0, nc)
+    n = V.nodes
+    rng = np.random.default_rng(21)
+    tl = (Nt + 1) * n
+    z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
+    if problem == "nonlinear":
+        u0 = hp.nonlinear_equation_IC(0, 1, 1.0 / nc, n, V.vertex_to_dof)
+        ic = (u0,)
+        ut, _ = otraj.solve_nonlinear_equation(np.full(tl, 0.5), z(u0), None, asm, n, Nt, dt)
+        targets = (ut[Nt * n:].copy(),)
+    elif problem == "schnak":
+        u0, v0 = hp.schnak_sys_IC(0, 1, 1.0 / nc, n, V.vertex_to_dof)
+        ic = (u0, v0)
+        ut, vt = otraj.solve_schnak_system(np.full(tl, 0.1), z(u0), z(v0), asm, n, Nt, dt)
+        targets = (ut[Nt * n:].copy(), vt[Nt * n:].copy())
+    else:
+        u0 = 1.5 + 0.1 * (0.5 - rng.random(n))
+        ic = (u0, u0.copy())
+        ut, vt = otraj.solve_chtxs_system(np.full(tl, 10.0), z(u0), z(u0), asm, n, Nt, dt)
+        targets = (ut.copy(), vt.copy())
+    return asm, V, ic, targets
+
+
+@pytest.mark.parametrize("speculative", [True, False])
+@pytest.mark.parametrize("problem,Nt,dt,opts", [
+    ("nonlinear", 10, 2e-3, dict(max_iter_GD=4)),
+    ("schnak", 8, 1e-3, dict(max_iter_GD=3)),                        # line searches hit max_iter: restore path
+    ("schnak", 8, 1e-3, dict(max_iter_GD=3, max_iter_armijo=14)),
+    ("chtxs", 8, 5e-4, dict(max_iter_GD=3, max_iter_armijo=8)),
+])
+def test_pgd_loop_matches_oracle_loop(hp, problem, Nt, dt, opts, speculative):
+    from oracle import pdeco as opdeco
+    asm, V, ic, targets = _setup(hp, problem, 12, Nt, dt)
+    ref = opdeco.projected_gradient_descent(problem, asm, asm.mass(), ic, targets, Nt, dt, **opts)
+    got = hp.projected_gradient_descent(problem, V, ic, targets, Nt, dt, speculative=speculative, **opts)
+    assert got["it"] == ref["it"] and got["restored"] == ref["restored"]
+    assert got["armijo_its"] == ref["armijo_its"]
+    np.testing.assert_allclose(got["cost"], ref["cost"], rtol=1e-9)
+    assert len(ref["cost"]) >= 2 and ref["cost"][-1] < ref["cost"][0]          # the loop did descend
+    for key in ("c", "u", "p") + (("v", "q") if problem != "nonlinear" else ()):
+        assert rel(got[key], ref[key]) < 1e-7, key
+
+
+def test_pgd_argument_errors(hp):
+    V = hp.SquareMeshP1(0.0, 1.0, 6)
+    with pytest.raises(ValueError):
+        hp.projected_gradient_descent("heat", V, (np.zeros(49),), (np.zeros(49),), 4, 1e-3)
+    with pytest.raises(TypeError):
+        hp.projected_gradient_descent("nonlinear", V, (np.zeros(49),), (np.zeros(49),), 4, 1e-3, stepsize=1)
+    with pytest.raises(ValueError):
+        hp.projected_gradient_descent("nonlinear", V, (np.zeros(49),), (np.zeros(49),), 4, 1e-3, optim="sometime")
+    with pytest.raises(ValueError):   # final-time problem needs final-time targets
+        hp.projected_gradient_descent("nonlinear", V, (np.zeros(49),), (np.zeros(5 * 49),), 4, 1e-3)

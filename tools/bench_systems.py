@@ -70,3 +70,39 @@ t = timeit(lambda: ctx.nonlinear_forward(Awn, cn, u, Nt, 1e-3, eps))
 print(f"nonlinear forward    : {Nt / t:8.0f} steps/s")
 t = timeit(lambda: ctx.nonlinear_adjoint(Awn, u, uh, p, Nt, 1e-3, eps))
 print(f"nonlinear adjoint    : {Nt / t:8.0f} steps/s")
+S.close()
+
+# ---------------------------------------------------------------------------------------------
+# whole projected-gradient iterations of the refactored drivers (pdeco.py), configs C3 / C4 sizes:
+# targets from the build's own forward solve at the true control, 3 PGD iterations each
+pdeco = importlib.import_module("fem-fct-pdeco_amd.pdeco")
+v2d = V.vertex_to_dof
+
+
+def targets_for(problem, ic, ctrue):
+    P = pdeco.SystemPDECO(problem, V, Nt, dt)
+    try:
+        c = P._up(np.full(tl, ctrue))
+        us = [P._up(np.concatenate([x0, np.zeros(Nt * n)])) for x0 in ic]
+        clev = P._zeros(n)
+        P._state(c, us[0], us[1] if len(us) > 1 else None, clev, 1)
+        out = [P._down(x) for x in us]
+    finally:
+        P.close()
+    return out
+
+
+for problem, ic, ctrue, optim in (
+        ("schnak", hp.schnak_sys_IC(0, 1, 0.025, n, v2d), 0.1, "finaltime"),
+        ("chtxs", (1.5 + 0.1 * (0.5 - np.random.default_rng(5).random(n)),) * 2, 10.0, "alltime")):
+    full = targets_for(problem, ic, ctrue)
+    tg = [x if optim == "alltime" else x[Nt * n:] for x in full]
+    for spec in (True, False):
+        with pdeco.SystemPDECO(problem, V, Nt, dt, max_iter_GD=3, tol=0.0) as P:
+            P.run(ic, tg, speculative=spec)          # warm-up: graphs, budgets
+        with pdeco.SystemPDECO(problem, V, Nt, dt, max_iter_GD=3, tol=0.0) as P:
+            t0 = time.perf_counter()
+            r = P.run(ic, tg, speculative=spec)
+            el = time.perf_counter() - t0
+        print(f"PGD {problem:7s} {'speculative' if spec else 'sequential '}: {el / max(r['it'], 1) * 1e3:8.1f} ms/iteration "
+              f"(armijo trials {r['armijo_its']}, cost {r['cost'][0]:.4e} -> {r['cost'][-1]:.4e})")
