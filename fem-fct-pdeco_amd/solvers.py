@@ -123,18 +123,39 @@ class SolidBodyDrift:
 
 def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower, c_upper, iters,
                             gam=1e-4, s0=1.0, max_armijo=10, speculative=True, tol=None):
-    """Projected gradient descent for the final-time drift-control problem, following the loop of
-    advection_solidbody_FCT_PDECO_finaltime_Garvie.py:164-330 step for step:
+    """Final-time variant of :func:`pgd_solidbody` (advection_solidbody_FCT_PDECO_finaltime_Garvie.py)."""
+    return pgd_solidbody(prob, u0, uhat_T, c0, beta, c_lower, c_upper, iters, gam, s0, max_armijo, speculative, tol,
+                         optim="finaltime")
+
+
+def pgd_solidbody_alltime(prob: SolidBodyDrift, u0, uhat_all, c0, beta, c_lower, c_upper, iters,
+                          gam=1e-4, s0=1.0, max_armijo=10, speculative=True, tol=None):
+    """All-time variant (advection_solidbody_FCT_PDECO_alltime_Garvie.py, config C5's loop): ``uhat_all``
+    is the target trajectory ((Nt+1)*n, level 0 = u0)."""
+    return pgd_solidbody(prob, u0, uhat_all, c0, beta, c_lower, c_upper, iters, gam, s0, max_armijo, speculative, tol,
+                         optim="alltime")
+
+
+def pgd_solidbody(prob: SolidBodyDrift, u0, uhat, c0, beta, c_lower, c_upper, iters,
+                  gam=1e-4, s0=1.0, max_armijo=10, speculative=True, tol=None, optim="finaltime"):
+    """Projected gradient descent for the drift-control problem, following the loop of
+    advection_solidbody_FCT_PDECO_finaltime_Garvie.py:164-330 / ..._alltime_Garvie.py:164-340 step for step:
 
         adjoint(c_prev, u) -> d = ChebSI(-(beta M c_prev + int p (b.grad u) v)) -> c = clip(c_prev + s0 d)
         -> state(c) -> J_k -> Armijo: trials c_inc = clip(c + s d), s = s0/2^k, accept the first with
         J(c_inc) - J_k <= -gam/s ||c_inc - c||^2_Q  (else the last) -> c_prev = c_inc
 
+    optim="finaltime": target uhat(T) (n values), p(T) = uhat_T - u(T), u(T) seeded with the target before
+    the first adjoint solve; optim="alltime": target trajectory, p(T) = 0, misfit load at every level,
+    u seeded with the whole target trajectory (alltime_Garvie.py: ``uk = np.copy(uhat_all)``).
     Everything stays in HBM; the host sees scalars only.  ``speculative=True`` evaluates all
     ``max_armijo`` trial steps as one batch of independent trajectories (same launches, B = max_armijo)
     and picks the first accepted one -- the iterate of the sequential search (each trial trajectory is
     the same computation; the states agree to the low-order solver tolerance, 1e-13).
     Returns ``(u, p, c, history)`` as NumPy arrays + a dict of per-iteration scalars."""
+    if optim not in ("alltime", "finaltime"):
+        raise ValueError(f"Invalid value for 'optim': '{optim}'. Must be one of ['alltime', 'finaltime'].")
+    alltime = optim == "alltime"
     ctx, n, Nt, dt, tl = prob.ctx, prob.n, prob.num_steps, prob.dt, prob.tlen
     B = int(max_armijo) if speculative else 1
     u = ctx.zeros(tl)
@@ -142,22 +163,27 @@ def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower,
     # the reference seeds u(T) with the target before the first adjoint solve (finaltime.py:146)
     p, d, c, rhs = ctx.zeros(tl), ctx.zeros(tl), ctx.zeros(tl), ctx.empty(tl)
     c_prev = ctx.array(np.asarray(c0, dtype=np.float64))
-    uh = ctx.array(uhat_T)
-    uhB = ctx.array(np.tile(np.asarray(uhat_T, dtype=np.float64), B))
+    uhat = np.asarray(uhat, dtype=np.float64).ravel()
+    if uhat.size != (tl if alltime else n):
+        raise ValueError(f"target of {uhat.size} values, expected {tl if alltime else n} for optim='{optim}'")
+    uh = ctx.array(uhat)
+    uhB = ctx.array(np.tile(uhat, B))
     cB, uB, ckB = ctx.zeros(B * tl), ctx.zeros(B * tl), ctx.zeros(B * tl)
     init = np.zeros((B, tl))
     init[:, :n] = u0
     uB.upload(init.reshape(-1))
     hist = dict(cost=[], armijo_k=[], step=[], rel_change=[])
-    # uk(T) = uhat_T initially (finaltime_Garvie.py: uk[num_steps*nodes:] = uhat_T)
-    u.copy_from(uh, n, dst_off=Nt * n)
+    if alltime:
+        u.copy_from(uh, tl - n, dst_off=n, src_off=n)      # uk = np.copy(uhat_all), level 0 = u0
+    else:
+        u.copy_from(uh, n, dst_off=Nt * n)                 # uk[num_steps*nodes:] = uhat_T
     try:
         for it in range(iters):
-            prob.adjoint(c_prev, u, uh, p, "finaltime", batch=1)
+            prob.adjoint(c_prev, u, uh, p, optim, batch=1)
             prob.descent_direction(c_prev, u, p, beta, d, scratch=rhs)
             ctx.project_control(c_prev, s0, d, c_lower, c_upper, c, tl)
             prob.forward(c, u, batch=1)
-            J_k = float(prob.cost(u, uh, c, beta, "finaltime", batch=1)[0])
+            J_k = float(prob.cost(u, uh, c, beta, optim, batch=1)[0])
             svals = [s0 * (1 / 2 ** k) for k in range(max_armijo)]
             accepted = None
             if speculative:
@@ -165,7 +191,7 @@ def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower,
                     ctx.project_control(c, s, d, c_lower, c_upper, cB.ptr + 8 * k * tl, tl)
                     ckB.copy_from(c, tl, dst_off=k * tl)
                 prob.forward(cB, uB, batch=B)
-                J = prob.cost(uB, uhB, cB, beta, "finaltime", batch=B)
+                J = prob.cost(uB, uhB, cB, beta, optim, batch=B)
                 stat = ctx.l2_norm_sq_Q(cB, ckB, Nt, dt, batch=B)
                 for k, s in enumerate(svals):
                     accepted = k
@@ -179,7 +205,7 @@ def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower,
                     accepted = k
                     ctx.project_control(c, s, d, c_lower, c_upper, cB, tl)
                     prob.forward(cB, uB, batch=1)
-                    J_acc = float(prob.cost(uB, uh, cB, beta, "finaltime", batch=1)[0])
+                    J_acc = float(prob.cost(uB, uh, cB, beta, optim, batch=1)[0])
                     stat = float(ctx.l2_norm_sq_Q(cB, c, Nt, dt)[0])
                     if not (J_acc - J_k > -gam / s * stat):
                         break

@@ -188,9 +188,10 @@ def _mass(hp, mesh):
     return P1Assembler(SquareMesh(mesh.a1, mesh.a2, mesh.n_cells)).mass()
 
 
-def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp, solvers):
-    """Projected gradient loop of advection_solidbody_FCT_PDECO_finaltime_Garvie.py:164-330 on the
-    device vs the same loop written with the CPU oracle."""
+@pytest.mark.parametrize("optim", ["finaltime", "alltime"])
+def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp, solvers, optim):
+    """Projected gradient loop of advection_solidbody_FCT_PDECO_finaltime_Garvie.py:164-330 (and of
+    ..._alltime_Garvie.py, config C5's loop) on the device vs the same loop written with the CPU oracle."""
     from oracle.mesh import SquareMesh
     from oracle.assembly import P1Assembler
     from oracle import traj as otraj, fct as ofct
@@ -208,20 +209,25 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
     # ---- oracle loop
     sb = otraj.SolidBody(asm, om=om)
     M = sb.cm.M
-    uk = np.zeros(tl); uk[:n] = u0; uk[Nt * n:] = uhat
+    if optim == "alltime":      # target trajectory: the oracle's own forward solve at the true control c = 2
+        uhat = np.zeros(tl); uhat[:n] = u0
+        otraj.solidbody_forward(sb, 2.0 * np.ones(tl), uhat, n, Nt, dt)
+        uk = uhat.copy()
+    else:
+        uk = np.zeros(tl); uk[:n] = u0; uk[Nt * n:] = uhat
     c_prev = c0.copy()
     costs, ks = [], []
     for it in range(iters):
-        pk = otraj.solidbody_adjoint(sb, c_prev, uk, uhat, np.zeros(tl), n, Nt, dt, optim="finaltime")
+        pk = otraj.solidbody_adjoint(sb, c_prev, uk, uhat, np.zeros(tl), n, Nt, dt, optim=optim)
         dk = otraj.solidbody_descent_direction(sb, c_prev, uk, pk, beta, n, Nt)
         ck = np.clip(c_prev + s0 * dk, lo, hi)
         otraj.solidbody_forward(sb, ck, uk, n, Nt, dt)
-        J_k = ofct.cost_functional(uk, uhat, ck, Nt, dt, M, beta, "finaltime")
+        J_k = ofct.cost_functional(uk, uhat, ck, Nt, dt, M, beta, optim)
         for k in range(max_armijo):
             s = s0 * (1 / 2 ** k)
             c_inc = np.clip(ck + s * dk, lo, hi)
             otraj.solidbody_forward(sb, c_inc, uk, n, Nt, dt)
-            J = ofct.cost_functional(uk, uhat, c_inc, Nt, dt, M, beta, "finaltime")
+            J = ofct.cost_functional(uk, uhat, c_inc, Nt, dt, M, beta, optim)
             stat = ofct.l2_norm_sq_Q(c_inc - ck, Nt, dt, M)
             if not (J - J_k > -gam / s * stat):
                 break
@@ -229,8 +235,9 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
         c_prev = c_inc
 
     prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1, 1, nc), Nt, dt, om=om)
-    u_s, p_s, c_s, h_s = solvers.pgd_solidbody_finaltime(prob, u0, uhat, c0, beta, lo, hi, iters, gam, s0, max_armijo, True)
-    u_q, p_q, c_q, h_q = solvers.pgd_solidbody_finaltime(prob, u0, uhat, c0, beta, lo, hi, iters, gam, s0, max_armijo, False)
+    pgd = solvers.pgd_solidbody_finaltime if optim == "finaltime" else solvers.pgd_solidbody_alltime
+    u_s, p_s, c_s, h_s = pgd(prob, u0, uhat, c0, beta, lo, hi, iters, gam, s0, max_armijo, True)
+    u_q, p_q, c_q, h_q = pgd(prob, u0, uhat, c0, beta, lo, hi, iters, gam, s0, max_armijo, False)
     assert h_s["armijo_k"] == ks and h_q["armijo_k"] == ks
     assert np.allclose(h_s["cost"], costs, rtol=1e-9, atol=0)
     assert rel(c_s, c_prev) < 1e-8 and rel(u_s, uk) < 1e-8
