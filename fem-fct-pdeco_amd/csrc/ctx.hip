@@ -166,7 +166,10 @@ int femfct_next_budget(const femfct_ctx* ctx, int worst, bool coarse) {
     int K;
     const int mode = fusion_mode(ctx, &K);
     int b;
-    if (mode == 2) b = std::max(worst, 1) + (coarse ? 0 : 1);             // exact count + one sweep of margin
+    // tiles: counts are whole launches (an upper bound) unless the exact-count variant ran, which gets one
+    // sweep of margin.  No margin otherwise: the halo depth is re-chosen from the budget, and a budget that
+    // creeps up by one per sweep walks through 2 x 12, 2 x 13, 3 x 9, 3 x 10, ... launches for nothing.
+    if (mode == 2) b = std::max(worst, 1) + ((coarse || !ctx->exact_iters) ? 0 : 1);
     else if (mode == 1) b = ((std::max(worst, 1) + K - 1) / K) * K;        // whole launches
     else b = std::max(8, worst + worst / 8 + 2);
     return std::min(ctx->max_iters, b);
@@ -175,7 +178,7 @@ int femfct_next_budget(const femfct_ctx* ctx, int worst, bool coarse) {
 int femfct_grow_budget(const femfct_ctx* ctx, int budget) {
     int K;
     const int mode = fusion_mode(ctx, &K);
-    if (mode == 2) return std::min(ctx->max_iters, budget + 3);
+    if (mode == 2) return std::min(ctx->max_iters, budget + 2);
     if (mode == 1) return std::min(ctx->max_iters, budget + K);
     return std::min(ctx->max_iters, budget * 2);
 }
@@ -213,6 +216,9 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_STRIP_K")) ctx->strip_k = atoi(e);
     if (const char* e = getenv("FEMFCT_TILES")) ctx->use_tiles = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_EXACT")) ctx->exact_iters = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_FUSE_BUILD")) ctx->fuse_build = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_DEEP_HALO")) ctx->deep_halo = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_FUSE_FLUX")) ctx->fuse_flux = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);

@@ -61,6 +61,7 @@ struct femfct_ctx {
     double rel_tol = 1e-13;
     int max_iters = 400;
     int sweep_budget = 48;      // adaptive: sweeps enqueued per step (stand-alone femfct_fct_step)
+    std::map<int, int> kind_fail;   // largest Jacobi budget known to be too small, per kind
     std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
@@ -68,6 +69,9 @@ struct femfct_ctx {
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
     int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always
     bool fuse_end = true;       // log + level advance done by the last workgroup of the step's final kernel
+    bool fuse_build = true;     // low-order operator construction inside the first tile-Jacobi launch (small grids)
+    bool deep_halo = true;      // Jacobi halos 11..13 while every tile gets its own CU (fewer launches)
+    bool fuse_flux = true;      // last Chebyshev iterations + flux + limiter in one tile launch (small grids)
     bool fuse_dudt = true;      // du/dt rhs + first Chebyshev iterations in one tile launch (small grids)
     bool exact_iters = false;   // last fused launch logs per-sweep residuals (exact sweep count; measured 10 % slower)
     int32_t bandwidth = 0;      // max |col - row| of the pattern
@@ -175,9 +179,12 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
                               double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1,
                               int32_t batch);
 struct TilePlan { int tiles, K, H; };
-bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true, int budget = 0);
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true, int budget = 0, int batch = 1);
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
-                               double* xb, int launch, int g_build, int32_t batch, bool last);
+                               double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch = 0);
+int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* A, const double* Nm, int32_t nshared,
+                                     struct VecRef rhs, int64_t rhs_bstride, struct VecRef u_n, int64_t u_bstride, double dt,
+                                     int32_t batch);
 bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl);   // more workgroups than in-kernel partials
 int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* b, const double* in_mid,
                              const double* in_old, double* y_out, int k_first, int k_last, const double* omegas,
@@ -187,7 +194,12 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
                                    struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end);
 int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
-                                  const double* omegas, double md_scale, int32_t batch);
+                                  const double* omegas, double md_scale, int32_t batch, int* tail_first = nullptr);
+bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch);
+int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old,
+                                        int k_first, int k_last, const double* omegas, double md_scale, const double* D,
+                                        const double* ulow, double dt, struct VecRef out, int64_t out_bstride, int32_t batch,
+                                        bool fuse_end);
 int femfct_tile4_init(femfct_ctx* ctx);
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
 int femfct_tile4_tiles(const femfct_ctx* ctx);

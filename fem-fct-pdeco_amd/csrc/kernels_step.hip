@@ -485,16 +485,20 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     LaunchGeom g = femfct_geom(ctx, batch);
     hipStream_t st = ctx->stream;
     int n = ctx->n, W = ctx->W;
-    LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n, rhs_bstride,
-             u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
     StripPlan pl;
     TilePlan tp;
     // Jacobi tiles: small grids reduce the residual partials in the consumer; large grids use the
     // extra reduce kernel (needs the big partial buffer, allocated by femfct_ensure_workspace)
-    const bool tiles = femfct_tile_plan(ctx, &tp, false, budget) && (!femfct_tile_big(ctx, tp) || ctx->d_bigpart);
+    const bool tiles = femfct_tile_plan(ctx, &tp, false, budget, batch) && (!femfct_tile_big(ctx, tp) || ctx->d_bigpart);
     const bool strips = !tiles && femfct_strip_plan(ctx, &pl);
     int units = budget, part_count = 0, ipu = 1, exact_k = 0;
     const bool tile4 = tiles && femfct_tile4_wanted(ctx, batch);
+    // latency regime: the operator construction rides in the first tile-Jacobi launch
+    const bool fused_build = ctx->fuse_build && tiles && !tile4 && !femfct_tile_big(ctx, tp) &&
+                             ctx->solver != FEMFCT_SOLVER_BICGSTAB && (budget + tp.K - 1) / tp.K >= 2;
+    if (!fused_build)
+        LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n,
+                 rhs_bstride, u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
     if (ctx->solver == FEMFCT_SOLVER_BICGSTAB) {
         // robust alternative for operators far from diagonal dominance: Jacobi-preconditioned BiCGStab
         // from x0 = u^n into d_xa; outcome mirrored into StepCtl (done, parity 0)
@@ -516,9 +520,12 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
         ipu = tp.K;
         exact_k = (femfct_tile_big(ctx, tp) || !ctx->exact_iters) ? 0 : tp.K;
-        for (int s = 0; s < units; ++s)
-            femfct_enqueue_tile_jacobi(ctx, tp, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch,
-                                       exact_k > 0 && s == units - 1);
+        if (fused_build)
+            femfct_enqueue_tile_build_jacobi(ctx, tp, A, N, nshared, rhs, rhs_bstride, u_n, u_bstride, dt, batch);
+        for (int s = fused_build ? 1 : 0; s < units; ++s)
+            femfct_enqueue_tile_jacobi(ctx, tp, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s,
+                                       fused_build ? tp.tiles * tp.tiles : (int)g.grid.x, batch,
+                                       exact_k > 0 && s == units - 1, fused_build ? 1 : 0);
     } else if (strips) {
         units = (budget + pl.K - 1) / pl.K;
         part_count = pl.S;
@@ -532,18 +539,34 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
     }
     // stable home of u_L for the flux/limit kernels: d_b (the low-order rhs is dead after the solve)
     double* ulow = ctx->d_b;
+    bool step_done = false;
     if (tiles && !tile4 && !femfct_tile_big(ctx, tp) && ctx->fuse_dudt) {
         std::vector<double> om;
         cheb_omegas(20, 0.5, 2.0, om);
+        int tail = 0;
+        const bool fuse_tail = femfct_cheb_flux_fusable(ctx, batch);
         femfct_enqueue_tile_dudt_cheb(ctx, A, rhs, rhs_bstride, ulow, units, part_count, ipu, exact_k, 20, om.data(), 1.25,
-                                      batch);
+                                      batch, fuse_tail ? &tail : nullptr);
+        if (fuse_tail && tail > 0) {
+            // iterations tail..20 of du/dt + flux + limiter (+ step end) in one launch
+            const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
+            int r = femfct_enqueue_tile_cheb_flux_limit(ctx, ctx->d_rdu, ctx->d_y0, ctx->d_y2, tail, 20, om.data(), 1.25,
+                                                        ctx->d_D, ulow, dt, u_out, out_bstride, batch, fuse_end);
+            if (r != FEMFCT_OK) return r;
+            if (fuse_end) ctx->end_fused = true;
+            step_done = true;
+        } else if (fuse_tail) {
+            return femfct_fail(ctx, FEMFCT_ERR_INVALID, "fused Chebyshev tail: nothing left to fuse");
+        }
     } else {
         LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
                  ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0,
                  exact_k ? ctx->d_partk : nullptr, exact_k);
         femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
     }
-    if (tiles) {
+    if (step_done) {
+        // limiter already ran inside the fused tail
+    } else if (tiles) {
         const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
         femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch, fuse_end);
         if (fuse_end) ctx->end_fused = true;

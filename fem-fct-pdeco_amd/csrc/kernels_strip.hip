@@ -307,6 +307,7 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
 #define TILE_H 8
 #define TILE_L 32
 #define TILE_LD 33   // padded LDS row
+#define TILE_HMAX 13 // deepest halo instantiated (Jacobi, latency regime)
 
 namespace {
 
@@ -353,7 +354,7 @@ template <int H, int EXACT, int BIG>
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
               double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-              int g_build, double rel_tol, double* __restrict__ bigpart, double* __restrict__ partk) {
+              int g_build, double rel_tol, double* __restrict__ bigpart, double* __restrict__ partk, int bn_launch) {
     constexpr int W = 7;
     __shared__ double xs[2][TILE_L * TILE_LD];
     __shared__ double smem[32];
@@ -363,7 +364,9 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
     double bnorm;
-    if (launch == 0) {
+    // ||b||, min row sum: reduced from the partials of the kernel that built L (k_build_low before launch 0,
+    // or the fused k_tile_build_jacobi = launch 0 itself, then bn_launch = 1)
+    if (launch == bn_launch) {
         bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
         double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
         if (wg == 0 && threadIdx.x == 0) {
@@ -373,6 +376,8 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
         }
     } else {
         bnorm = ctl->bnorm;
+    }
+    if (launch > 0) {
         double rmax = BIG ? ctl->rs[(launch - 1) & 1]
                           : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
@@ -460,6 +465,132 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     if (threadIdx.x == 0) {
         if (BIG) bigpart[(int64_t)bz * nwg + wg] = rmax;
         else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+    }
+}
+
+// Launch 0 of the low-order solve with the construction of the low-order operator folded in
+// (what k_build_low does, helpers.py:1769-1780, same expressions in the same order => bitwise the same
+// L, D, b): every thread builds the row of its patch node from A (a_ji comes from the neighbour thread
+// through LDS, three slots at a time), the tile's owned rows are stored for the later launches / the
+// limiter, then K Jacobi sweeps run as in k_tile_jacobi.  Saves one dependent launch per time step.
+template <int H>
+__global__ void __launch_bounds__(STRIP_T)
+k_tile_build_jacobi(int n, int N, const double* __restrict__ A_, const double* __restrict__ N_, int nshared,
+                    VecRef rhs_ref, int64_t rhs_bstride, VecRef u_ref, int64_t u_bstride,
+                    const double* __restrict__ ml, double dt, double* __restrict__ L_, double* __restrict__ D_,
+                    double* __restrict__ b_, double* __restrict__ xb_, double* __restrict__ part,
+                    StepCtl* __restrict__ ctl_, int K) {
+    constexpr int W = 7;
+    __shared__ double xs[2][TILE_L * TILE_LD];
+    __shared__ double as[3][TILE_L * TILE_LD];
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    if (wg == 0 && threadIdx.x == 0) {
+        StepCtl* c = ctl_ + bz;
+        c->flags = 0; c->iters = 0; c->done = 0; c->parity = 0; c->resid = 0.0; c->bnorm = 0.0;
+        c->min_rowsum = 0.0;
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* A = A_ + moff;
+    const double* Nm = N_ ? N_ + (nshared ? 0 : moff) : nullptr;
+    const double* rhs = vec_ptr(rhs_ref);
+    if (rhs) rhs += bz * rhs_bstride;
+    const double* u = vec_ptr(u_ref) + bz * u_bstride;
+    const TileGeom g = tile_geom<TILE_L - 2 * H, H>(N);
+    // neighbour s exists in the grid (otherwise the ELL slot is padding: column = row, value 0)
+    const int dx[6] = {1, 1, 0, -1, -1, 0}, dy[6] = {0, 1, 1, 0, -1, -1};
+    bool ex[W - 1];
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) {
+        const int nx = g.gx + dx[s], ny = g.gy + dy[s];
+        ex[s] = g.inside && nx >= 0 && nx < N && ny >= 0 && ny < N;
+    }
+    double av[W - 1], at[W - 1], a0 = 0.0;
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) av[s] = 0.0;
+    if (g.inside) {
+        a0 = A[g.i];
+#pragma unroll
+        for (int s = 1; s < W; ++s) av[s - 1] = A[(int64_t)s * n + g.i];
+    }
+    // a_ji of slot s lives in row j at the opposite slot: slots E,NE,N <-> W,SW,S
+#pragma unroll
+    for (int s = 0; s < 3; ++s) as[s][g.self] = av[s + 3];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) at[s] = as[s][g.nb[s]];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) as[s][g.self] = av[s];
+    __syncthreads();
+#pragma unroll
+    for (int s = 3; s < 6; ++s) at[s] = as[s - 3][g.nb[s]];
+    double lv[W - 1], dv[W - 1], dsum = 0.0, rs = 0.0;
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) {
+        const double a = av[s];
+        const double d = ex[s] ? fmax(0.0, fmax(a, at[s])) : 0.0;   // d_ij = max(0, a_ij, a_ji)
+        dsum += d;
+        double l = dt * (a - d);
+        if (Nm && g.inside) l += dt * Nm[(int64_t)(s + 1) * n + g.i];
+        lv[s] = l;
+        dv[s] = d;
+        rs += l;
+    }
+    double dg = 1.0, rdg = 1.0, bv = 0.0, xi = 0.0;
+    if (g.inside) {
+        const double mli = ml[g.i];
+        double ld = mli + dt * (a0 + dsum);                         // d_ii = -sum_j d_ij
+        if (Nm) ld += dt * Nm[g.i];
+        rs += ld;
+        dg = ld;
+        rdg = 1.0 / dg;
+        xi = u[g.i];
+        bv = mli * xi + (rhs ? dt * rhs[g.i] : 0.0);
+    }
+    double bmax = 0.0, rsmin = INFINITY;
+    if (g.owned) {
+        double* L = L_ + moff;
+        double* D = D_ + moff;
+        L[g.i] = dg;
+        D[g.i] = -dsum;
+#pragma unroll
+        for (int s = 1; s < W; ++s) {
+            L[(int64_t)s * n + g.i] = lv[s - 1];
+            D[(int64_t)s * n + g.i] = dv[s - 1];
+        }
+        b_[voff + g.i] = bv;
+        bmax = fabs(bv);
+        rsmin = rs;
+    }
+    xs[0][g.self] = xi;
+    __syncthreads();
+    double rmax = 0.0;
+    int cur = 0;
+    for (int k = 0; k < K; ++k) {
+        const double* c = xs[cur];
+        double xn = c[g.self];
+        if (k < g.kvalid) {
+            double acc = bv;
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+            if (k == K - 1 && g.owned) rmax = fmax(rmax, fabs(acc - dg * xn));
+            xn = acc * rdg;
+        }
+        xs[cur ^ 1][g.self] = xn;
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (g.owned) xb_[voff + g.i] = xs[cur][g.self];
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    bmax = block_reduce(bmax, OpMax(), 0.0, smem);
+    rsmin = block_reduce(rsmin, OpMin(), INFINITY, smem);
+    if (threadIdx.x == 0) {
+        p[wg] = rmax;
+        p[2 * FEMFCT_MAX_PARTIALS + wg] = bmax;
+        p[3 * FEMFCT_MAX_PARTIALS + wg] = rsmin;
     }
 }
 
@@ -630,6 +761,154 @@ k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __re
 
 }  // namespace
 
+namespace {
+
+// The last <= 10 Chebyshev iterations of du/dt (helpers.py:175-184) and the whole limiter
+// (helpers.py:1818-1870) in one launch: 8 x 8 tile + halo 12 (ten rings for the iterations, two for
+// the limiter: R+- of the ring-1 neighbours).  du never goes to memory.  Same expressions in the same
+// order as k_tile_cheb + k_tile_flux_limit => bitwise the same step.  Latency regime only.
+__global__ void __launch_bounds__(STRIP_T)
+k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double* __restrict__ b_,
+                       const double* __restrict__ ymid_, const double* __restrict__ yold_, int K, CheOmegas om,
+                       double md_scale, const double* __restrict__ D_, const double* __restrict__ ulow_,
+                       const double* __restrict__ ml, double dt, VecRef out_ref, int64_t out_bstride, EndArgs e) {
+    constexpr int W = 7, HH = 12;
+    __shared__ double ys[3][TILE_L * TILE_LD];
+    __shared__ double su[TILE_L * TILE_LD], srp[TILE_L * TILE_LD], srm[TILE_L * TILE_LD];
+    const int bz = blockIdx.z;
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const TileGeom g = tile_geom<TILE_L - 2 * HH, HH>(N);
+    double mv[W - 1], dv[W - 1], md = 1.0, rmd = 1.0, bv = 0.0, ym = 0.0, yo = 0.0, ui = 0.0, mli = 1.0;
+#pragma unroll
+    for (int s = 0; s < W - 1; ++s) { mv[s] = 0.0; dv[s] = 0.0; }
+    if (g.inside) {
+        md = M[g.i];
+        rmd = 1.0 / (md_scale * md);
+#pragma unroll
+        for (int s = 1; s < W; ++s) mv[s - 1] = M[(int64_t)s * n + g.i];
+        bv = b_[voff + g.i];
+        ym = ymid_[voff + g.i];
+        yo = yold_[voff + g.i];
+#pragma unroll
+        for (int s = 1; s < W; ++s) dv[s - 1] = D_[moff + (int64_t)s * n + g.i];
+        ui = ulow_[voff + g.i];
+        mli = ml[g.i];
+    }
+    ys[0][g.self] = yo;
+    ys[1][g.self] = ym;
+    su[g.self] = ui;
+    srp[g.self] = 1.0;
+    srm[g.self] = 1.0;
+    __syncthreads();
+    int io = 0, im = 1, in_ = 2;
+    for (int k = 0; k < K; ++k) {
+        const double* ymd = ys[im];
+        const double ymv = ymd[g.self];
+        double yn = ymv;
+        if (k < g.kvalid) {
+            double acc = md * ymv;
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
+            const double z = (bv - acc) * rmd;
+            const double yov = ys[io][g.self];
+            yn = om.w[k] * (z + ymv - yov) + yov;
+        }
+        ys[in_][g.self] = yn;
+        __syncthreads();
+        int t = io; io = im; im = in_; in_ = t;
+    }
+    const double* sd = ys[im];
+    const double dui = sd[g.self];
+    double f[W - 1];
+    // fluxes where all six neighbours carry the final du (one ring inside the iterations' validity)
+    const bool have = g.inside && g.kvalid >= K + 1;
+    if (have) {
+        double pp = 0.0, pm = 0.0, umax = ui, umin = ui;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) {
+            const double uj = su[g.nb[s]];
+            const double mij = mv[s], dij = dv[s];
+            const double fs = mij * (dui - sd[g.nb[s]]) + dij * (ui - uj);
+            f[s] = fs;
+            pp += fmax(fs, 0.0);
+            pm += fmin(fs, 0.0);
+            const bool live = (mij != 0.0) || (dij != 0.0);
+            umax = live ? fmax(umax, uj) : umax;
+            umin = live ? fmin(umin, uj) : umin;
+        }
+        const double qp = umax - ui, qm = umin - ui;
+        srp[g.self] = (pp != 0.0) ? fmin(1.0, mli * qp / (dt * pp)) : 1.0;
+        srm[g.self] = (pm != 0.0) ? fmin(1.0, mli * qm / (dt * pm)) : 1.0;
+    }
+    __syncthreads();
+    if (g.owned) {
+        const double rpi = srp[g.self], rmi = srm[g.self];
+        double fbar = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) {
+            const double fs = f[s];
+            const double a = (fs > 0.0) ? fmin(rpi, srm[g.nb[s]]) : fmin(rmi, srp[g.nb[s]]);
+            fbar += a * fs;
+        }
+        double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
+        out[g.i] = ui + dt * fbar / mli;
+    }
+    if (e.level) {
+        __shared__ int is_last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+            is_last = (atomicAdd(e.ticket, 1u) == total - 1);
+        }
+        __syncthreads();
+        if (is_last) {
+            const int ord = e.level[1];
+            for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
+                e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
+                if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                e.level[0] += e.delta;
+                e.level[1] = ord + 1;
+                *e.ticket = 0u;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// one workgroup per CU is the regime where the fused tail pays (see femfct_tile_plan)
+bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch) {
+    if (!ctx->fuse_flux || ctx->N > 512) return false;
+    const int t = (ctx->N + 7) / 8;
+    return (int64_t)t * t * batch <= 256;
+}
+
+int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old,
+                                        int k_first, int k_last, const double* omegas, double md_scale, const double* D,
+                                        const double* ulow, double dt, VecRef out, int64_t out_bstride, int32_t batch,
+                                        bool fuse_end) {
+    const int K = k_last - k_first + 1;
+    if (K < 1 || K > 10) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "fused Chebyshev tail: %d iterations", K);
+    EndArgs e;
+    e.level = nullptr;
+    if (fuse_end) {
+        e.level = ctx->d_level; e.delta = ctx->end_req_delta; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
+        e.kctl = ctx->end_req_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr; e.klog = (KrylovCtl*)ctx->d_klog;
+        e.batch = batch; e.ticket = ctx->d_ticket;
+    }
+    CheOmegas om;
+    for (int k = k_first; k <= k_last; ++k) om.w[k - k_first] = omegas[k - 1];
+    const int t = (ctx->N + 7) / 8;
+    femfct_prof_begin(ctx, KC_FLUX);
+    hipLaunchKernelGGL(k_tile_cheb_flux_limit, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b,
+                       in_mid, in_old, K, om, md_scale, D, ulow, ctx->d_ml, dt, out, out_bstride, e);
+    femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
                                    VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end) {
     EndArgs e;
@@ -658,21 +937,26 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
 // (Chebyshev: 19 remaining iterations = 10 + 9 with H = 10).  Bandwidth regime (large grids): H = 8
 // keeps the halo re-reading lowest.  need_partials: the Jacobi variant publishes one residual partial
 // per workgroup, consumed in-kernel up to FEMFCT_MAX_PARTIALS workgroups (else a reduce kernel).
-bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials, int budget) {
+bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials, int budget, int batch) {
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
     int H = 8;
     const bool small = ctx->N <= 512;
     if (small) {
         if (budget <= 0) H = 10;
         else {
+            // fewest launches first, then the smallest halo.  Deep halos (11..13: tiles of 10..6 nodes per
+            // side) only while every workgroup still gets its own CU -- there a launch costs ~4.4 us fixed
+            // + ~0.3 us per sweep whatever the tile size (tools/lat_probe.hip), so 2 x 13 beats 3 x 9.
             int best = 1 << 30;
-            for (int h = 8; h <= 10; ++h) {
+            for (int h = 8; h <= TILE_HMAX; ++h) {
+                const int T = TILE_L - 2 * h, t = (ctx->N + T - 1) / T;
+                if (h > 10 && (!ctx->deep_halo || (int64_t)t * t * batch > 256)) break;
                 int launches = (budget + h - 1) / h;
                 if (launches < best) { best = launches; H = h; }
             }
         }
     }
-    if (small && ctx->strip_k >= 8 && ctx->strip_k <= 10) H = ctx->strip_k;   // tuning knob (latency regime only)
+    if (small && ctx->strip_k >= 8 && ctx->strip_k <= TILE_HMAX) H = ctx->strip_k;   // tuning knob (latency regime only)
     const int T = TILE_L - 2 * H;
     const int t = (ctx->N + T - 1) / T;
     if (need_partials && (int64_t)t * t > FEMFCT_MAX_PARTIALS) return false;
@@ -687,8 +971,27 @@ bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl) {
     return (int64_t)pl.tiles * pl.tiles > FEMFCT_MAX_PARTIALS;
 }
 
+// launch 0 with the operator construction fused in (latency regime; needs >= 2 launches in total because
+// ||b|| is reduced by launch 1).  Later launches: femfct_enqueue_tile_jacobi(..., bn_launch = 1, g_build = tiles^2).
+int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* A, const double* Nm, int32_t nshared,
+                                     VecRef rhs, int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt,
+                                     int32_t batch) {
+    dim3 grid(pl.tiles, pl.tiles, batch);
+    femfct_prof_begin(ctx, KC_JACOBI);
+#define TB(HH) hipLaunchKernelGGL((k_tile_build_jacobi<HH>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, A, Nm,  \
+                                  nshared, rhs, rhs_bstride, u_n, u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, \
+                                  ctx->d_xb, ctx->d_part, ctx->d_ctl, pl.K)
+    switch (pl.H) {
+        case 8: TB(8); break; case 9: TB(9); break; case 10: TB(10); break;
+        case 11: TB(11); break; case 12: TB(12); break; default: TB(13); break;
+    }
+#undef TB
+    femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
-                               double* xb, int launch, int g_build, int32_t batch, bool last) {
+                               double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch) {
     const bool big = femfct_tile_big(ctx, pl);
     double* bigp = big ? ctx->d_bigpart : nullptr;
     double* pk = (last && !big) ? ctx->d_partk : nullptr;
@@ -697,13 +1000,16 @@ int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double
 #define TJ(HH)                                                                                                          \
     do {                                                                                                                \
         if (big) hipLaunchKernelGGL((k_tile_jacobi<8, 0, 1>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,  \
-                                    xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);    \
+                                    xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch); \
         else if (pk) hipLaunchKernelGGL((k_tile_jacobi<HH, 1, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, \
-                                        b, xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk); \
+                                        b, xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch); \
         else hipLaunchKernelGGL((k_tile_jacobi<HH, 0, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, \
-                                xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk);            \
+                                xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch); \
     } while (0)
-    if (pl.H == 8) TJ(8); else if (pl.H == 9) TJ(9); else TJ(10);
+    switch (pl.H) {
+        case 8: TJ(8); break; case 9: TJ(9); break; case 10: TJ(10); break;
+        case 11: TJ(11); break; case 12: TJ(12); break; default: TJ(13); break;
+    }
 #undef TJ
     if (big)
         hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart,
@@ -834,9 +1140,11 @@ k_tile_dudt_cheb(int n, int N, const double* __restrict__ A_, VecRef rhs_ref, in
 }  // namespace
 
 // r, y_1 and Chebyshev iterations 2..(K+1) in one launch, the rest in ceil(.../10) tile launches.
+// tail_first (optional): the caller runs the remaining iterations *tail_first .. iters itself (inputs
+// mid = d_y0, old = d_y2), e.g. fused with the limiter; 0 is stored when nothing remains.
 int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
-                                  const double* omegas, double md_scale, int32_t batch) {
+                                  const double* omegas, double md_scale, int32_t batch, int* tail_first) {
     constexpr int H = 10;
     const int T = TILE_L - 2 * H, t = (ctx->N + T - 1) / T;
     const int K = std::min(iters - 1, H - 1);            // iterations 2..K+1 here
@@ -851,7 +1159,8 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, VecRef rhs, 
                        budget_units, part_count, iters_per_unit, ctx->rel_tol, exact_k ? ctx->d_partk : nullptr, exact_k,
                        K, om, md_scale, omegas[0]);
     femfct_prof_end(ctx);
-    if (last) return FEMFCT_OK;
+    if (tail_first) *tail_first = last ? 0 : K + 2;
+    if (last || tail_first) return FEMFCT_OK;
     TilePlan tp;
     tp.H = H; tp.K = H; tp.tiles = t;
     // remaining iterations K+2 .. iters; inputs (mid, old) = (y0, y2); scratch pair (y1, rp) then (y0, y2)

@@ -101,6 +101,25 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
                     kbudget, worst, kworst, (int)short_budget, (int)kshort);
         if (!short_budget && !kshort) {
             ctx->kind_budget[kind] = femfct_next_budget(ctx, worst, coarse);
+            // Tiles report whole launches: `worst` = U launches of K sweeps, and every step was still above
+            // the tolerance after (U-1)*K.  If one launch fewer of the deepest halo could cover that, try it
+            // once (a failure is remembered per kind and costs one repeated sweep).
+            TilePlan tp, tp2;
+            if (femfct_tile_plan(ctx, &tp, false, budget, batch) && !femfct_tile4_wanted(ctx, batch) && worst > 0) {
+                const int U = (worst + tp.K - 1) / tp.K, lb = (U - 1) * tp.K;
+                for (int b_try = lb + 1; U >= 2 && b_try < worst; ++b_try) {
+                    if (!femfct_tile_plan(ctx, &tp2, false, b_try, batch)) break;
+                    if ((b_try + tp2.K - 1) / tp2.K > U - 1) continue;
+                    // largest budget that still fits U-1 launches
+                    int top = (U - 1) * tp2.K;
+                    while (femfct_tile_plan(ctx, &tp2, false, top + 1, batch) && (top + 1 + tp2.K - 1) / tp2.K <= U - 1 &&
+                           top + 1 < worst)
+                        ++top;
+                    const int known_fail = ctx->kind_fail.count(kind) ? ctx->kind_fail[kind] : 0;
+                    if (top > lb && top > known_fail && 10 * top >= 7 * worst) ctx->kind_budget[kind] = top;
+                    break;
+                }
+            }
             // (Chebyshev reports the count that meets tol/10 at its asymptotic rate: no extra margin)
             if (krylov)
                 ctx->kind_kbudget[kkey] = std::min(ctx->kry_max_iters, cheb ? std::max(8, kworst + 1)
@@ -108,6 +127,7 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
             return FEMFCT_OK;
         }
         if (short_budget) {
+            ctx->kind_fail[kind] = std::max(ctx->kind_fail.count(kind) ? ctx->kind_fail[kind] : 0, budget);
             if (budget >= ctx->max_iters)
                 return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
                                    "low-order solve: residual %.3e after %d Jacobi sweeps (tol %.1e)", worst_res,

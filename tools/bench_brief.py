@@ -20,5 +20,5 @@ if "roofline" in d:
         f"{k}={v['achieved_GBps']:.0f}GB/s({v['avg_launch_ms'] * 1e3:.0f}us x{v['launches']})" for k, v in r["kernels"].items())
 if "pgd_c2" in d:
     g = d["pgd_c2"]
-    msg += f" | PGD: spec {g['speculative']['s_per_pgd_iteration']*1e3:.1f} ms/iter, seq {g['sequential']['s_per_pgd_iteration']*1e3:.1f} ms/iter, trials {g['sequential']['armijo_trials']}, same={g['same_iterates']}"
+    msg += f" | PGD: spec {g['speculative']['s_per_pgd_iteration']*1e3:.1f} ms/iter, seq {g['sequential']['s_per_pgd_iteration']*1e3:.1f} ms/iter, trials {g['sequential']['armijo_trials']}, dJ={g.get('cost_rel_diff')}"
 print(msg)
