@@ -76,6 +76,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_hout); dev_free(&ctx->d_hcsr);
     femfct_mesh_release(ctx);
     ctx->h_indptr.clear(); ctx->h_indices.clear(); ctx->h_csr2ell.clear(); ctx->h_cols.clear();
+    dev_free(&ctx->d_trAall); ctx->trAall_count = 0;
     dev_free(&ctx->d_trA); dev_free(&ctx->d_trN); dev_free(&ctx->d_trRhs); dev_free(&ctx->d_level); dev_free(&ctx->d_log);
     dev_free(&ctx->d_ticket);
     ctx->tr_batch = 0; ctx->tr_steps = 0;
@@ -217,6 +218,8 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_TILES")) ctx->use_tiles = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_EXACT")) ctx->exact_iters = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_BUILD")) ctx->fuse_build = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_PREASSEMBLE")) ctx->preassemble = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_PREASSEMBLE_MAX_GB")) ctx->preassemble_max_bytes = atof(e) * 1024.0 * 1024.0 * 1024.0;
     if (const char* e = getenv("FEMFCT_DEEP_HALO")) ctx->deep_halo = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_FLUX")) ctx->fuse_flux = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;

@@ -23,6 +23,21 @@ __device__ __forceinline__ const double* vec_ptr(const VecRef& r) {
     return r.base + lv * r.stride;
 }
 
+// A per-step matrix (ELL values) that may be one of a pre-assembled sequence indexed by the device-side
+// time level: address = base + (*level + level_off) * lstride + batch_member * bstride.
+struct MatRef {
+    const double* base;
+    const int32_t* level;   // null: a single matrix
+    int64_t lstride;
+    int32_t level_off;
+    int64_t bstride;        // batch stride (0: shared by the batch)
+};
+
+__device__ __forceinline__ const double* mat_ptr(const MatRef& r, int bz) {
+    int64_t lv = r.level ? (int64_t)(*r.level) + r.level_off : 0;
+    return r.base + lv * r.lstride + (int64_t)bz * r.bstride;
+}
+
 // Optional overrides of the tile Chebyshev kernels (species solves inside trajectory sweeps): another
 // matrix than the mass matrix (per batch member), a level-indirected start iterate / destination.
 struct ChebIO {

@@ -99,6 +99,10 @@ struct femfct_ctx {
 
     // trajectory workspace
     int32_t tr_batch = 0, tr_steps = 0;
+    double* d_trAall = nullptr;     // pre-assembled per-level operators of a sweep [members][Nt][W*n]
+    size_t trAall_count = 0;
+    bool preassemble = true;
+    double preassemble_max_bytes = 16.0 * 1024 * 1024 * 1024;
     double *d_trA = nullptr, *d_trN = nullptr, *d_trRhs = nullptr;  // per-step operators [B*W*n], [B*n]
     int32_t* d_level = nullptr;                                     // [2]: current level, step ordinal
     StepCtl* d_log = nullptr;                                       // [tr_steps * tr_batch]
@@ -182,7 +186,7 @@ struct TilePlan { int tiles, K, H; };
 bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true, int budget = 0, int batch = 1);
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
                                double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch = 0);
-int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* A, const double* Nm, int32_t nshared,
+int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, struct MatRef A, const double* Nm, int32_t nshared,
                                      struct VecRef rhs, int64_t rhs_bstride, struct VecRef u_n, int64_t u_bstride, double dt,
                                      int32_t batch);
 bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl);   // more workgroups than in-kernel partials
@@ -192,7 +196,7 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
                              const struct ChebIO* io = nullptr);
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
                                    struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end);
-int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
+int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, struct MatRef A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch, int* tail_first = nullptr);
 bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch);

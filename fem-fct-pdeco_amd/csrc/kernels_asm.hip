@@ -113,10 +113,14 @@ __global__ void k_quad_points(int nc, double a1, double h, double* __restrict__ 
 __global__ void k_ops_solidbody(int n, int N, int nc, double h, const int32_t* __restrict__ d2v,
                                 const int32_t* __restrict__ cols, const double* __restrict__ Ad,
                                 const double* __restrict__ Arot, VecRef c_ref, int64_t c_bstride, double eps,
-                                double sigma, double rot_scale, double bx, double by, double* __restrict__ A_) {
-    const int bz = blockIdx.y;
-    const double* c = vec_ptr(c_ref) + bz * c_bstride;
-    double* A = A_ + (int64_t)bz * STENCIL_W * n;
+                                double sigma, double rot_scale, double bx, double by, double* __restrict__ A_,
+                                int levels) {
+    // levels = 1: the operator of the current level (c_ref is level-indirected).  levels > 1: every level
+    // at once, blockIdx.y = member * levels + k uses control level c_ref.level_off + k (c_ref.level unused).
+    const int bz = blockIdx.y / levels, lk = blockIdx.y - bz * levels;
+    const double* c = (levels > 1 ? c_ref.base + (int64_t)(c_ref.level_off + lk) * c_ref.stride : vec_ptr(c_ref)) +
+                      bz * c_bstride;
+    double* A = A_ + (int64_t)blockIdx.y * STENCIL_W * n;
     RowRange rr = block_rows(n);
     const double m12 = 0.5 * h * h / 12.0;
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
@@ -231,11 +235,13 @@ int femfct_enqueue_mesh_constants(femfct_ctx* ctx) {
 }
 
 int femfct_enqueue_ops_solidbody(femfct_ctx* ctx, const double* Arot, VecRef c_ref, int64_t c_bstride, double eps,
-                                 double sigma, double rot_scale, double bx, double by, double* A, int32_t batch) {
-    LaunchGeom g = femfct_geom(ctx, batch);
+                                 double sigma, double rot_scale, double bx, double by, double* A, int32_t batch,
+                                 int32_t levels) {
+    LaunchGeom g = femfct_geom(ctx, batch * levels);
     femfct_prof_begin(ctx, KC_ASSEMBLE);
     hipLaunchKernelGGL(k_ops_solidbody, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->N, ctx->n_cells, ctx->h,
-                       ctx->d_d2v, ctx->d_cols, ctx->d_Ad, Arot, c_ref, c_bstride, eps, sigma, rot_scale, bx, by, A);
+                       ctx->d_d2v, ctx->d_cols, ctx->d_Ad, Arot, c_ref, c_bstride, eps, sigma, rot_scale, bx, by, A,
+                       levels);
     femfct_prof_end(ctx);
     return FEMFCT_OK;
 }

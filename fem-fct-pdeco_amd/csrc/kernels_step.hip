@@ -65,7 +65,7 @@ __device__ __forceinline__ int tslot_of(const uint8_t* __restrict__ tslot, int n
 // ---------------------------------------------------------------------------
 template <int WT, int BS, int IMP>
 __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const int32_t* __restrict__ cols,
-                            const uint8_t* __restrict__ tslot, const double* __restrict__ A_,
+                            const uint8_t* __restrict__ tslot, MatRef A_ref,
                             const double* __restrict__ N_, int nshared, VecRef rhs_ref, VecRef u_ref,
                             int64_t rhs_bstride, int64_t u_bstride,
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
     const int W = WT ? WT : Wrt;
     const int bz = blockIdx.y;
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
-    const double* A = A_ + moff;
+    const double* A = mat_ptr(A_ref, bz);
     const double* Nm = N_ ? N_ + (nshared ? 0 : moff) : nullptr;
     const double* rhs = vec_ptr(rhs_ref);
     if (rhs) rhs += bz * rhs_bstride;
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int
 // (y_1 = omega_1 * r / (1.25 diag M), helpers.py:175-182 with y_0 = y_-1 = 0).
 // ---------------------------------------------------------------------------
 template <int WT, int BS, int IMP>
-__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ A_,
+__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, MatRef A_ref,
                            VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
                            const double* __restrict__ xa_, const double* __restrict__ xb_,
                            double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
     finalize_solve(ctl, p, part_count ? part_count : (int)gridDim.x, budget, iters_per_unit, rel_tol, smem,
                    partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, blockIdx.x == 0);
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
-    const double* A = A_ + moff;
+    const double* A = mat_ptr(A_ref, bz);
     const double* x = (parity ? xb_ : xa_) + voff;
     const double* rhs = vec_ptr(rhs_ref);
     if (rhs) rhs += bz * rhs_bstride;
@@ -479,7 +479,19 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
 }
 
 // Enqueue the whole step with level-indirected in/out vectors (trajectory drivers) --------
+int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t nshared, VecRef rhs, int64_t rhs_bstride,
+                            VecRef u_n, int64_t u_bstride, double dt, VecRef u_out, int64_t out_bstride, int32_t batch,
+                            int32_t budget);
+
 int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, VecRef rhs,
+                            int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
+                            int64_t out_bstride, int32_t batch, int32_t budget) {
+    return femfct_enqueue_step_mat(ctx, MatRef{A, nullptr, 0, 0, (int64_t)ctx->W * ctx->n}, N, nshared, rhs, rhs_bstride, u_n,
+                                   u_bstride, dt, u_out, out_bstride, batch, budget);
+}
+
+// A: the flux matrix of this step, possibly one of a pre-assembled per-level sequence (MatRef)
+int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t nshared, VecRef rhs,
                             int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
                             int64_t out_bstride, int32_t batch, int32_t budget) {
     LaunchGeom g = femfct_geom(ctx, batch);

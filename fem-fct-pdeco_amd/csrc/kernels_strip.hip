@@ -475,7 +475,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
 // limiter, then K Jacobi sweeps run as in k_tile_jacobi.  Saves one dependent launch per time step.
 template <int H>
 __global__ void __launch_bounds__(STRIP_T)
-k_tile_build_jacobi(int n, int N, const double* __restrict__ A_, const double* __restrict__ N_, int nshared,
+k_tile_build_jacobi(int n, int N, MatRef A_ref, const double* __restrict__ N_, int nshared,
                     VecRef rhs_ref, int64_t rhs_bstride, VecRef u_ref, int64_t u_bstride,
                     const double* __restrict__ ml, double dt, double* __restrict__ L_, double* __restrict__ D_,
                     double* __restrict__ b_, double* __restrict__ xb_, double* __restrict__ part,
@@ -493,7 +493,7 @@ k_tile_build_jacobi(int n, int N, const double* __restrict__ A_, const double* _
         c->min_rowsum = 0.0;
     }
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
-    const double* A = A_ + moff;
+    const double* A = mat_ptr(A_ref, bz);
     const double* Nm = N_ ? N_ + (nshared ? 0 : moff) : nullptr;
     const double* rhs = vec_ptr(rhs_ref);
     if (rhs) rhs += bz * rhs_bstride;
@@ -973,7 +973,7 @@ bool femfct_tile_big(const femfct_ctx* ctx, const TilePlan& pl) {
 
 // launch 0 with the operator construction fused in (latency regime; needs >= 2 launches in total because
 // ||b|| is reduced by launch 1).  Later launches: femfct_enqueue_tile_jacobi(..., bn_launch = 1, g_build = tiles^2).
-int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* A, const double* Nm, int32_t nshared,
+int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, MatRef A, const double* Nm, int32_t nshared,
                                      VecRef rhs, int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt,
                                      int32_t batch) {
     dim3 grid(pl.tiles, pl.tiles, batch);
@@ -1061,7 +1061,7 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
 namespace {
 
 __global__ void __launch_bounds__(STRIP_T)
-k_tile_dudt_cheb(int n, int N, const double* __restrict__ A_, VecRef rhs_ref, int64_t rhs_bstride,
+k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride,
                  const double* __restrict__ M, const double* __restrict__ xa_, const double* __restrict__ xb_,
                  double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ omid_,
                  double* __restrict__ oold_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget,
@@ -1077,7 +1077,8 @@ k_tile_dudt_cheb(int n, int N, const double* __restrict__ A_, VecRef rhs_ref, in
     const int parity = ctl->done ? ctl->parity : (budget & 1);
     finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
                    partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
-    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const int64_t voff = (int64_t)bz * n;
+    const double* A = mat_ptr(A_ref, bz);
     const double* x = (parity ? xb_ : xa_) + voff;
     const double* rhs = vec_ptr(rhs_ref);
     if (rhs) rhs += bz * rhs_bstride;
@@ -1091,7 +1092,7 @@ k_tile_dudt_cheb(int n, int N, const double* __restrict__ A_, VecRef rhs_ref, in
         md = M[g.i];
         rmd = 1.0 / (md_scale * md);
 #pragma unroll
-        for (int s = 0; s < W; ++s) av[s] = A_[moff + (int64_t)s * n + g.i];
+        for (int s = 0; s < W; ++s) av[s] = A[(int64_t)s * n + g.i];
 #pragma unroll
         for (int s = 1; s < W; ++s) mv[s - 1] = M[(int64_t)s * n + g.i];
         ui = x[g.i];
@@ -1142,7 +1143,7 @@ k_tile_dudt_cheb(int n, int N, const double* __restrict__ A_, VecRef rhs_ref, in
 // r, y_1 and Chebyshev iterations 2..(K+1) in one launch, the rest in ceil(.../10) tile launches.
 // tail_first (optional): the caller runs the remaining iterations *tail_first .. iters itself (inputs
 // mid = d_y0, old = d_y2), e.g. fused with the limiter; 0 is stored when nothing remains.
-int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, const double* A, VecRef rhs, int64_t rhs_bstride, double* ulow,
+int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, MatRef A, VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch, int* tail_first) {
     constexpr int H = 10;

@@ -20,7 +20,34 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
                             int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
                             int64_t out_bstride, int32_t batch, int32_t budget);
 int femfct_enqueue_ops_solidbody(femfct_ctx* ctx, const double* Arot, VecRef c_ref, int64_t c_bstride, double eps,
-                                 double sigma, double rot_scale, double bx, double by, double* A, int32_t batch);
+                                 double sigma, double rot_scale, double bx, double by, double* A, int32_t batch,
+                                 int32_t levels = 1);
+
+// The solid-body operator depends on the control only, which is given for the whole sweep: assemble the
+// matrices of all time levels in one launch before the sweep (HBM is large: Nt * 7n doubles per control
+// trajectory, 92 MB at C2) instead of one small dependent launch per step.  Returns false (per-step
+// assembly) when the sequence would not fit the configured cap or the launch grid.
+static bool solidbody_preassemble(femfct_ctx* ctx, const double* Arot, const double* c_traj, int32_t c_shared,
+                                  int64_t tstride, int32_t c_level0, double eps, double sigma, double rot_scale, double bx,
+                                  double by, int32_t num_steps, int32_t batch, MatRef* out) {
+    const int32_t members = c_shared ? 1 : batch;
+    const size_t count = (size_t)members * num_steps * ctx->W * ctx->n;
+    if (!ctx->preassemble || (double)count * 8.0 > ctx->preassemble_max_bytes) return false;
+    if ((int64_t)members * num_steps > 65535) return false;
+    if (count > ctx->trAall_count) {
+        femfct_drop_graphs(ctx);
+        if (ctx->d_trAall) hipFree(ctx->d_trAall);
+        ctx->d_trAall = nullptr; ctx->trAall_count = 0;
+        if (hipMalloc((void**)&ctx->d_trAall, sizeof(double) * count) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ctx->trAall_count = count;
+    }
+    const int64_t n = ctx->n;
+    femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, nullptr, n, c_level0), c_shared ? 0 : tstride, eps, sigma,
+                                 rot_scale, bx, by, ctx->d_trAall, members, num_steps);
+    const int64_t wn = (int64_t)ctx->W * n;
+    *out = MatRef{ctx->d_trAall, ctx->d_level, wn, 0, c_shared ? 0 : wn * num_steps};
+    return true;
+}
 int femfct_enqueue_mass_diff(femfct_ctx* ctx, VecRef a, int64_t a_bstride, VecRef b, int64_t b_bstride, double* out,
                              int32_t batch);
 int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
@@ -121,17 +148,29 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
     const int64_t n = ctx->n, tstride = (int64_t)(num_steps + 1) * n;
     const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;  // any valid ELL array; multiplied by 0
     int32_t* lv = ctx->d_level;
-    auto begin = [&]() { return FEMFCT_OK; };
+    MatRef Aall{};
+    bool pre = false;
+    // step k (level counter k) uses the control of level k+1 (finaltime.py:185): sequence entry k
+    auto begin = [&]() {
+        pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 1, eps, -1.0, rot_scale, bx, by, num_steps, batch,
+                                    &Aall);
+        return FEMFCT_OK;
+    };
     auto step = [&](int budget, int, int reps) {
         femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
-                                 key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
+                                 key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol),
+                                 key_bits(pre ? Aall.base : nullptr)};
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
-            femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
-                                         rot_scale, bx, by, ctx->d_trA, batch);
+            MatRef A = Aall;
+            if (!pre) {
+                femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
+                                             rot_scale, bx, by, ctx->d_trA, batch);
+                A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
+            }
             femfct_request_fused_end(ctx, 1, false);
-            int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, make_ref(nullptr), 0,
+            int r = femfct_enqueue_step_mat(ctx, A, nullptr, 0, make_ref(nullptr), 0,
                                             make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
                                             tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
@@ -153,7 +192,12 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
     const int64_t n = ctx->n, tstride = (int64_t)(num_steps + 1) * n;
     const double* Arot = Arot_ell ? Arot_ell : ctx->d_Ad;
     int32_t* lv = ctx->d_level;
+    MatRef Aall{};
+    bool pre = false;
     auto begin = [&]() {
+        // level counter n uses the control of level n (finaltime.py:213): sequence entry n
+        pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 0, eps, +1.0, rot_scale, bx, by, num_steps, batch,
+                                    &Aall);
         // terminal condition: p(T) = uhat_T - u(T) (finaltime.py:201) or 0 (alltime.py:232)
         for (int32_t b = 0; b < batch; ++b) {
             double* pT = p_traj + b * tstride + (int64_t)num_steps * n;
@@ -166,11 +210,15 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
         femfct_ctx::GraphKey key{(uint64_t)3, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(uhat), key_bits(p_traj), key_bits(num_steps), key_bits(dt), key_bits(eps),
                                  key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
-                                 key_bits((int32_t)budget), key_bits(ctx->rel_tol)};
+                                 key_bits((int32_t)budget), key_bits(ctx->rel_tol), key_bits(pre ? Aall.base : nullptr)};
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // level counter = n: control c_n (finaltime.py:213), p_{n+1} -> p_n
-            femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
-                                         rot_scale, bx, by, ctx->d_trA, batch);
+            MatRef A = Aall;
+            if (!pre) {
+                femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
+                                             rot_scale, bx, by, ctx->d_trA, batch);
+                A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
+            }
             VecRef rhs = make_ref(nullptr);
             if (alltime) {  // rhs = assemble((uhat_n - u_n) v dx)  (alltime.py:257)
                 femfct_enqueue_mass_diff(ctx, make_ref(uhat, lv, n, 0), tstride, make_ref(u_traj, lv, n, 0), tstride,
@@ -178,7 +226,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
                 rhs = make_ref(ctx->d_trRhs);
             }
             femfct_request_fused_end(ctx, -1, false);
-            int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
+            int r = femfct_enqueue_step_mat(ctx, A, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
                                             dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
             femfct_enqueue_step_end(ctx, -1, batch, false);

@@ -16,6 +16,9 @@ void femfct_request_fused_end(femfct_ctx* ctx, int delta, bool with_krylov);
 int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, VecRef rhs,
                             int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
                             int64_t out_bstride, int32_t batch, int32_t budget);
+int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t nshared, VecRef rhs, int64_t rhs_bstride,
+                            VecRef u_n, int64_t u_bstride, double dt, VecRef u_out, int64_t out_bstride, int32_t batch,
+                            int32_t budget);
 int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
                          double* out);
 
