@@ -278,7 +278,8 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     ctx.set_profiling(False)
     log = prob.solver_log(1)
     sweeps = int(log["solver_iters"].sum())
-    units = {"jacobi": sweeps, "cheb": 19 * steps}          # sweeps / iterations actually executed
+    # sweeps / iterations / levels actually executed (the operators of all levels are assembled in one launch)
+    units = {"jacobi": sweeps, "cheb": 19 * steps, "assemble": steps}
     fused_flux = rep["limit"][1] == 0                       # flux + limit in one launch
     bpr = dict(BYTES_PER_ROW)
     if fused_flux:

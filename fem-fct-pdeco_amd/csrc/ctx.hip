@@ -225,6 +225,8 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
+    if (const char* e = getenv("FEMFCT_T4_DPP")) ctx->t4_dpp = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_T4_K")) ctx->t4_k = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("FEMFCT_SPECIES_SOLVER")) ctx->species_solver = atoi(e);
     if (const char* e = getenv("FEMFCT_STEPS_PER_GRAPH")) ctx->steps_per_graph = std::max(1, atoi(e));
     return femfct_strip_init(ctx);

@@ -67,6 +67,8 @@ struct femfct_ctx {
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
+    int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always
     bool fuse_end = true;       // log + level advance done by the last workgroup of the step's final kernel
     bool fuse_build = true;     // low-order operator construction inside the first tile-Jacobi launch (small grids)

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            acc -= L[idx] * xin[col_of<IMP>(cols, n, Nw, mask, s, i)];
+            acc = fma(-L[idx], xin[col_of<IMP>(cols, n, Nw, mask, s, i)], acc);
         }
         double ld = L[i];
         double xi = xin[i];
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
-            acc += A[idx] * x[col_of<IMP>(cols, n, Nw, mask, s, i)];
+            acc = fma(A[idx], x[col_of<IMP>(cols, n, Nw, mask, s, i)], acc);
         }
         double r = -acc + (rhs ? rhs[i] : 0.0);
         rdu[i] = r;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, int Nw, const int32
 #pragma unroll
             for (int s = 1; s < W; ++s) {
                 int64_t idx = (int64_t)s * n + i;
-                acc += M[idx] * ymid[col_of<IMP>(cols, n, Nw, mask, s, i)];
+                acc = fma(M[idx], ymid[col_of<IMP>(cols, n, Nw, mask, s, i)], acc);
             }
         }
         double r = b[i] - acc;
@@ -522,9 +522,10 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
     } else if (tile4) {
         const int t4 = femfct_tile4_tiles(ctx);
         const bool big4 = (int64_t)t4 * t4 > FEMFCT_MAX_PARTIALS;
-        units = (budget + 7) / 8;
+        const int k4 = ctx->t4_k;       // sweeps per launch (8; fewer only as a measurement knob)
+        units = (budget + k4 - 1) / k4;
         part_count = big4 ? -1 : t4 * t4;
-        ipu = 8;
+        ipu = k4;
         for (int s = 0; s < units; ++s)
             femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
     } else if (tiles) {

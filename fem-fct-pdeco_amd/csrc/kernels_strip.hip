@@ -101,7 +101,7 @@ k_strip_jacobi(int n, const int32_t* __restrict__ cols, const double* __restrict
                 if (li >= lo && li < hi) {
                     double acc = bv[r];
 #pragma unroll
-                    for (int s = 1; s < W; ++s) acc -= lv[r][s] * cur[lc[r][s - 1]];
+                    for (int s = 1; s < W; ++s) acc = fma(-lv[r][s], cur[lc[r][s - 1]], acc);
                     xn = acc * lv[r][0];          // one reciprocal per row and launch instead of K divisions
                     const int i = e0 + li;
                     if (k == K - 1 && i >= r0 && i < r1) rmax = fmax(rmax, fabs(acc - dg[r] * xi));
@@ -181,7 +181,7 @@ k_strip_cheb(int n, const int32_t* __restrict__ cols, const double* __restrict__
                 if (li >= lo && li < hi) {
                     double acc = mv[r][0] * ym;
 #pragma unroll
-                    for (int s = 1; s < W; ++s) acc += mv[r][s] * y_mid[lc[r][s - 1]];
+                    for (int s = 1; s < W; ++s) acc = fma(mv[r][s], y_mid[lc[r][s - 1]], acc);
                     const double rr = bv[r] - acc;
                     const double z = rr * rmd[r];
                     const double yo = y_old[li];
@@ -415,7 +415,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
             if (k < g.kvalid) {
                 double acc = bv;
 #pragma unroll
-                for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+                for (int s = 0; s < W - 1; ++s) acc = fma(-lv[s], c[g.nb[s]], acc);
                 if (k == K - 1 && g.owned) rmax = fmax(rmax, fabs(acc - dg * xn));
                 xn = acc * rdg;
             }
@@ -436,7 +436,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
                 if (k < g.kvalid) {
                     double acc = bv;
 #pragma unroll
-                    for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+                    for (int s = 0; s < W - 1; ++s) acc = fma(-lv[s], c[g.nb[s]], acc);
                     if (g.owned) rk[k] = fabs(acc - dg * xn);
                     if (k == K - 1) rmax = fmax(rmax, rk[k]);
                     xn = acc * rdg;
@@ -575,7 +575,7 @@ k_tile_build_jacobi(int n, int N, MatRef A_ref, const double* __restrict__ N_, i
         if (k < g.kvalid) {
             double acc = bv;
 #pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc -= lv[s] * c[g.nb[s]];
+            for (int s = 0; s < W - 1; ++s) acc = fma(-lv[s], c[g.nb[s]], acc);
             if (k == K - 1 && g.owned) rmax = fmax(rmax, fabs(acc - dg * xn));
             xn = acc * rdg;
         }
@@ -644,7 +644,7 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
         if (k < g.kvalid) {
             double acc = md * ymv;
 #pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
+            for (int s = 0; s < W - 1; ++s) acc = fma(mv[s], ymd[g.nb[s]], acc);
             const double z = (bv - acc) * rmd;
             const double yov = ys[io][g.self];
             const double wk = omd ? omd[k] : om.w[k];
@@ -808,7 +808,7 @@ k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double*
         if (k < g.kvalid) {
             double acc = md * ymv;
 #pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
+            for (int s = 0; s < W - 1; ++s) acc = fma(mv[s], ymd[g.nb[s]], acc);
             const double z = (bv - acc) * rmd;
             const double yov = ys[io][g.self];
             yn = om.w[k] * (z + ymv - yov) + yov;
@@ -1105,7 +1105,7 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
     if (g.kvalid >= 1) {
         double acc = av[0] * ui;
 #pragma unroll
-        for (int s = 1; s < W; ++s) acc += av[s] * ys[2][g.nb[s - 1]];
+        for (int s = 1; s < W; ++s) acc = fma(av[s], ys[2][g.nb[s - 1]], acc);
         r = -acc + ri;
         y1 = omega1 * (r / (md_scale * md));
     }
@@ -1121,7 +1121,7 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         if (k + 1 < g.kvalid) {      // one ring already spent on A u_L
             double acc = md * ymv;
 #pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc += mv[s] * ymd[g.nb[s]];
+            for (int s = 0; s < W - 1; ++s) acc = fma(mv[s], ymd[g.nb[s]], acc);
             const double z = (r - acc) * rmd;
             const double yov = ys[io][g.self];
             yn = om.w[k] * (z + ymv - yov) + yov;
@@ -1287,7 +1287,7 @@ k_tile4_jacobi(int n, int N, const double* __restrict__ L_, const double* __rest
             if (k < g[q].kvalid) {
                 double acc = bv[q];
 #pragma unroll
-                for (int s = 0; s < W - 1; ++s) acc -= lv[q][s] * cur[g[q].self + t4_off(s)];
+                for (int s = 0; s < W - 1; ++s) acc = fma(-lv[q][s], cur[g[q].self + t4_off(s)], acc);
                 if (k == K - 1 && g[q].owned) rmax = fmax(rmax, fabs(acc - dg[q] * xn));
                 xn = acc * rdg[q];
             }
@@ -1350,7 +1350,7 @@ k_tile4_cheb(int n, int N, const double* __restrict__ M, const double* __restric
             if (k < g[q].kvalid) {
                 double acc = md[q] * ymv;
 #pragma unroll
-                for (int s = 0; s < W - 1; ++s) acc += mv[q][s] * y_mid[g[q].self + t4_off(s)];
+                for (int s = 0; s < W - 1; ++s) acc = fma(mv[q][s], y_mid[g[q].self + t4_off(s)], acc);
                 const double z = (bv[q] - acc) * rmd[q];
                 const double yov = y_old[g[q].self];
                 const double wk = omd ? omd[k] : om.w[k];
@@ -1366,6 +1366,212 @@ k_tile4_cheb(int n, int N, const double* __restrict__ M, const double* __restric
         if (g[q].owned) {
             omid_[voff + g[q].i] = y_mid[g[q].self];
             if (oold_) oold_[voff + g[q].i] = y_old[g[q].self];
+        }
+}
+
+// -------------------------------------------------------------------------------------------
+// Register-resident variant of the 64 x 64 patch kernels.  A wave owns a 64-wide, 4-row strip; a
+// thread keeps its four (vertically adjacent) iterate values in registers.  Vertical neighbours are the
+// thread's own registers, E/NE/W/SW come from the neighbouring lanes by wave-wide DPP shifts
+// (wave_shl:1 / wave_shr:1, tools/dpp_probe.hip) and only the strip's first and last row go through LDS
+// (2 writes + 2 reads per thread and sweep instead of 24 reads + 4 writes): the sweeps of the LDS
+// variant cost ~10 us each over a 2049^2 mesh and were not overlapped with the matrix load
+// (1 workgroup per CU at 104 VGPRs).  Same expressions in the same order => bitwise the same iterates.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp_from_next(double v) {   // lane i <- lane i+1 (lane 63 <- 0)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_prev(double v) {   // lane i <- lane i-1 (lane 0 <- 0)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+struct Strip4Node {
+    int i, kvalid;
+    bool inside, owned;
+};
+
+__device__ __forceinline__ Strip4Node strip4_node(int N, int r) {
+    Strip4Node g;
+    const int lx = threadIdx.x & 63, ly = 4 * (threadIdx.x >> 6) + r;
+    const int x0 = blockIdx.x * T4_T - T4_H, y0 = blockIdx.y * T4_T - T4_H;
+    const int gx = x0 + lx, gy = y0 + ly;
+    g.inside = gx >= 0 && gx < N && gy >= 0 && gy < N;
+    g.i = g.inside ? gy * N + gx : 0;
+    g.owned = g.inside && lx >= T4_H && lx < T4_H + T4_T && ly >= T4_H && ly < T4_H + T4_T;
+    int kv = 1 << 20;
+    if (x0 > 0) kv = min(kv, lx);
+    if (x0 + T4_L - 1 < N - 1) kv = min(kv, T4_L - 1 - lx);
+    if (y0 > 0) kv = min(kv, ly);
+    if (y0 + T4_L - 1 < N - 1) kv = min(kv, T4_L - 1 - ly);
+    g.kvalid = g.inside ? kv : 0;
+    return g;
+}
+
+// the six neighbour values of the thread's node r from registers / lane shifts / the two LDS rows
+#define STRIP4_NEIGHBOURS(X, ABOVE, BELOW)                                                          \
+    double e_[4], w_[4];                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) { e_[r] = dpp_from_next(X[r]); w_[r] = dpp_from_prev(X[r]); } \
+    const double ea_ = dpp_from_next(ABOVE), wb_ = dpp_from_prev(BELOW)
+#define STRIP4_NB(X, ABOVE, BELOW, r, s)                                                            \
+    ((s) == 0 ? e_[r] : (s) == 1 ? ((r) < 3 ? e_[((r) + 1) & 3] : ea_) : (s) == 2 ? ((r) < 3 ? X[((r) + 1) & 3] : ABOVE) \
+     : (s) == 3 ? w_[r] : (s) == 4 ? ((r) > 0 ? w_[((r) + 3) & 3] : wb_) : ((r) > 0 ? X[((r) + 3) & 3] : BELOW))
+
+template <int BIG>
+__global__ void __launch_bounds__(STRIP_T)
+k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
+                double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
+                int g_build, double rel_tol, double* __restrict__ bigpart) {
+    constexpr int W = 7;
+    __shared__ double top[2][16][64], bot[2][16][64];
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    double bnorm;
+    if (launch == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        if (wg == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rmax = BIG ? ctl->rs[(launch - 1) & 1]
+                          : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        if (rmax <= rel_tol * bnorm) {
+            if (wg == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
+                ctl->resid = bnorm > 0.0 ? rmax / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
+    double* xout = ((launch & 1) ? xa_ : xb_) + voff;
+    const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
+    Strip4Node g[4];
+    double lv[4][W - 1], dg[4], rdg[4], bv[4], x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        g[r] = strip4_node(N, r);
+        dg[r] = 1.0; rdg[r] = 1.0; bv[r] = 0.0; x[r] = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) lv[r][s] = 0.0;
+        if (g[r].inside) {
+            dg[r] = L[g[r].i];
+            rdg[r] = 1.0 / dg[r];
+#pragma unroll
+            for (int s = 1; s < W; ++s) lv[r][s - 1] = L[(int64_t)s * n + g[r].i];
+            bv[r] = b_[voff + g[r].i];
+            x[r] = xin[g[r].i];
+        }
+    }
+    double rmax = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int par = k & 1;
+        bot[par][st][lx] = x[0];
+        top[par][st][lx] = x[3];
+        __syncthreads();
+        const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+        const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+        STRIP4_NEIGHBOURS(x, above, below);
+        double xn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xn[r] = x[r];
+            double acc = bv[r];
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc = fma(-lv[r][s], STRIP4_NB(x, above, below, r, s), acc);
+            if (k < g[r].kvalid) {
+                if (k == K - 1 && g[r].owned) rmax = fmax(rmax, fabs(acc - dg[r] * x[r]));
+                xn[r] = acc * rdg[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = xn[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (g[r].owned) xout[g[r].i] = x[r];
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) {
+        if (BIG) bigpart[(int64_t)bz * nwg + wg] = rmax;
+        else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+    }
+}
+
+__global__ void __launch_bounds__(STRIP_T)
+k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
+              const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
+              CheOmegas om, double md_scale, ChebIO cio) {
+    constexpr int W = 7;
+    __shared__ double top[2][16][64], bot[2][16][64];
+    if (cio.mat) M = cio.mat + (int64_t)blockIdx.z * cio.mat_bs;
+    if (cio.scale_dev) md_scale = cio.scale_dev[blockIdx.z];
+    const double* omd = cio.om_dev ? cio.om_dev + (int64_t)blockIdx.z * cio.om_bs + cio.k0 : nullptr;
+    if (cio.mid_ref.base) ymid_ = vec_ptr(cio.mid_ref) + (int64_t)blockIdx.z * cio.mid_bs - (int64_t)blockIdx.z * n;
+    if (cio.out_ref.base) omid_ = const_cast<double*>(vec_ptr(cio.out_ref)) + (int64_t)blockIdx.z * cio.out_bs - (int64_t)blockIdx.z * n;
+    const int64_t voff = (int64_t)blockIdx.z * n;
+    const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
+    Strip4Node g[4];
+    double mv[4][W - 1], md[4], rmd[4], bv[4], ym[4], yo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        g[r] = strip4_node(N, r);
+        md[r] = 1.0; rmd[r] = 1.0; bv[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) mv[r][s] = 0.0;
+        if (g[r].inside) {
+            md[r] = M[g[r].i];
+            rmd[r] = 1.0 / (md_scale * md[r]);
+#pragma unroll
+            for (int s = 1; s < W; ++s) mv[r][s - 1] = M[(int64_t)s * n + g[r].i];
+            bv[r] = b_[voff + g[r].i];
+            if (ymid_) ym[r] = ymid_[voff + g[r].i];
+            if (yold_) yo[r] = yold_[voff + g[r].i];
+        }
+    }
+    for (int k = 0; k < K; ++k) {
+        const int par = k & 1;
+        bot[par][st][lx] = ym[0];
+        top[par][st][lx] = ym[3];
+        __syncthreads();
+        const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+        const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+        STRIP4_NEIGHBOURS(ym, above, below);
+        const double wk = omd ? omd[k] : om.w[k];
+        double yn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            yn[r] = ym[r];
+            double acc = md[r] * ym[r];
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) acc = fma(mv[r][s], STRIP4_NB(ym, above, below, r, s), acc);
+            if (k < g[r].kvalid) {
+                const double z = (bv[r] - acc) * rmd[r];
+                yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (g[r].owned) {
+            omid_[voff + g[r].i] = ym[r];
+            if (oold_) oold_[voff + g[r].i] = yo[r];
         }
 }
 
@@ -1395,14 +1601,24 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     dim3 grid(t, t, batch);
     const size_t lds = (size_t)2 * T4_BUF * 8;
     femfct_prof_begin(ctx, KC_JACOBI);
-    if (big) {
+    if (ctx->t4_dpp) {
+        if (big) {
+            hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
+                               ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, ctx->d_bigpart);
+            hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
+                               ctx->d_ctl, launch);
+        } else {
+            hipLaunchKernelGGL(k_strip4_jacobi<0>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
+                               ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, (double*)nullptr);
+        }
+    } else if (big) {
         hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                           ctx->d_ctl, launch, T4_H, g_build, ctx->rel_tol, ctx->d_bigpart);
+                           ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, ctx->d_bigpart);
         hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                            ctx->d_ctl, launch);
     } else {
         hipLaunchKernelGGL(k_tile4_jacobi<0>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                           ctx->d_ctl, launch, T4_H, g_build, ctx->rel_tol, (double*)nullptr);
+                           ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, (double*)nullptr);
     }
     femfct_prof_end(ctx);
     return FEMFCT_OK;
@@ -1431,8 +1647,12 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
-        hipLaunchKernelGGL(k_tile4_cheb, dim3(t, t, batch), dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
-                           old, omid, oold, k1 - k0, om, md_scale, io);
+        if (ctx->t4_dpp)
+            hipLaunchKernelGGL(k_strip4_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
+                               old, omid, oold, k1 - k0, om, md_scale, io);
+        else
+            hipLaunchKernelGGL(k_tile4_cheb, dim3(t, t, batch), dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
+                               old, omid, oold, k1 - k0, om, md_scale, io);
         femfct_prof_end(ctx);
         mid = omid;
         old = oold;
