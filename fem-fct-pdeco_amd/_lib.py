@@ -100,6 +100,7 @@ SIGNATURES = {
     "femfct_assemble_convection": (C.c_int, [_p, _p, _d, _p]),
     "femfct_drift_gradient_rhs": (C.c_int, [_p, _p, _p, _p, _d, _d, _d, _p, _i]),
     "femfct_solidbody_forward": (C.c_int, [_p, _p, _p, _i, _p, _i, _d, _d, _d, _d, _d, _i]),
+    "femfct_solidbody_forward_src": (C.c_int, [_p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _d, _i]),
     "femfct_solidbody_adjoint": (C.c_int, [_p, _p, _p, _i, _p, _p, _p, _i, _d, _d, _d, _d, _d, _i, _i]),
     "femfct_traj_info": (C.c_int, [_p, C.POINTER(StepInfo), _i, _i]),
     "femfct_descent_pointwise": (C.c_int, [_p, C.c_int64, _d, _p, _d, _p, _p, _d, _p]),

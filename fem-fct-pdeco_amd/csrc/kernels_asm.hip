@@ -160,15 +160,16 @@ __global__ void k_mass_diff(int n, int W, const int32_t* __restrict__ cols, cons
                             double* __restrict__ out_) {
     const int bz = blockIdx.y;
     const double* a = vec_ptr(a_ref) + bz * a_bstride;
-    const double* b = vec_ptr(b_ref) + bz * b_bstride;
+    const double* b = vec_ptr(b_ref);           // may be absent: out = M a
+    if (b) b += bz * b_bstride;
     double* out = out_ + (int64_t)bz * n;
     RowRange rr = block_rows(n);
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
-        double acc = M[i] * (a[i] - b[i]);
+        double acc = M[i] * (a[i] - (b ? b[i] : 0.0));
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
             int j = cols[idx];
-            acc += M[idx] * (a[j] - b[j]);
+            acc += M[idx] * (a[j] - (b ? b[j] : 0.0));
         }
         out[i] = acc;
     }

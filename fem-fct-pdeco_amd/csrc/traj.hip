@@ -140,6 +140,15 @@ extern "C" {
 int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
                              double* u_traj, int32_t num_steps, double dt, double eps, double rot_scale, double bx,
                              double by, int32_t batch) {
+    return femfct_solidbody_forward_src(ctx, Arot_ell, c_traj, c_shared, nullptr, u_traj, num_steps, dt, eps, rot_scale, bx,
+                                        by, batch);
+}
+
+// the same sweep with a source trajectory: rhs_{n+1} = assemble(src_{n+1} * v * dx) = M src_{n+1}
+// (advection_FCT_PDECO_alltime_exact.py:249-253: u_rhs = assemble((g_np1 + c_np1)*v*dx), A_u = A - eps*Ad)
+int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
+                                 const double* src_traj, double* u_traj, int32_t num_steps, double dt, double eps,
+                                 double rot_scale, double bx, double by, int32_t batch) {
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
     ARG_TRY(ctx, c_traj && u_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
     ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
@@ -160,7 +169,7 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
         femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
                                  key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol),
-                                 key_bits(pre ? Aall.base : nullptr)};
+                                 key_bits(pre ? Aall.base : nullptr), key_bits(src_traj)};
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
             MatRef A = Aall;
@@ -169,8 +178,13 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
                                              rot_scale, bx, by, ctx->d_trA, batch);
                 A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
             }
+            VecRef rhs = make_ref(nullptr);
+            if (src_traj) {
+                femfct_enqueue_mass_diff(ctx, make_ref(src_traj, lv, n, 1), tstride, make_ref(nullptr), 0, ctx->d_trRhs, batch);
+                rhs = make_ref(ctx->d_trRhs);
+            }
             femfct_request_fused_end(ctx, 1, false);
-            int r = femfct_enqueue_step_mat(ctx, A, nullptr, 0, make_ref(nullptr), 0,
+            int r = femfct_enqueue_step_mat(ctx, A, nullptr, 0, rhs, n,
                                             make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
                                             tstride, batch, budget);
             if (r != FEMFCT_OK) return r;

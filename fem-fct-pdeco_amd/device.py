@@ -259,10 +259,10 @@ class Context:
 
     # -- trajectories ------------------------------------------------------------------
     def solidbody_forward(self, Arot, c_traj, u_traj, num_steps, dt, eps=0.0, rot_scale=1.0,
-                          drift=(1.0, 1.0), batch=1, c_shared=False):
-        check(self.handle, lib.femfct_solidbody_forward(
-            self.handle, dptr(Arot), dptr(c_traj), int(bool(c_shared)), dptr(u_traj), int(num_steps), float(dt),
-            float(eps), float(rot_scale), float(drift[0]), float(drift[1]), int(batch)))
+                          drift=(1.0, 1.0), batch=1, c_shared=False, src_traj=None):
+        check(self.handle, lib.femfct_solidbody_forward_src(
+            self.handle, dptr(Arot), dptr(c_traj), int(bool(c_shared)), dptr(src_traj), dptr(u_traj), int(num_steps),
+            float(dt), float(eps), float(rot_scale), float(drift[0]), float(drift[1]), int(batch)))
 
     def solidbody_adjoint(self, Arot, c_traj, u_traj, uhat, p_traj, num_steps, dt, eps=0.0, rot_scale=1.0,
                           drift=(1.0, 1.0), alltime=False, batch=1, c_shared=False):

@@ -49,10 +49,11 @@ class SolidBodyDrift:
     def new_traj(self, batch=None) -> DeviceArray:
         return self.ctx.zeros(self.tlen * (self.batch if batch is None else batch))
 
-    def forward(self, c: DeviceArray, u: DeviceArray, batch=None, c_shared=False):
-        """u level 0 holds the IC; fills levels 1..Nt."""
+    def forward(self, c: DeviceArray, u: DeviceArray, batch=None, c_shared=False, src=None):
+        """u level 0 holds the IC; fills levels 1..Nt.  ``src``: optional source trajectory, the step to
+        level n+1 gets rhs = assemble(src_{n+1}*v*dx) (advection_FCT_PDECO_alltime_exact.py:249-253)."""
         self.ctx.solidbody_forward(self.Arot, c, u, self.num_steps, self.dt, self.eps, self.rot_scale,
-                                   self.drift, self.batch if batch is None else batch, c_shared)
+                                   self.drift, self.batch if batch is None else batch, c_shared, src_traj=src)
 
     def adjoint(self, c, u, uhat, p, optim="finaltime", batch=None, c_shared=False):
         if optim not in ("alltime", "finaltime"):
@@ -119,6 +120,46 @@ class SolidBodyDrift:
 
     def close(self):
         self.ctx.close()
+
+
+class LinearSourceControl(SolidBodyDrift):
+    """Linear advection-diffusion with a distributed source control, the problem family of
+    advection_FCT_PDECO_{alltime,finaltime}[_exact].py:  A_u = A - eps*Ad (state), A_p = -A - eps*Ad (adjoint),
+    state rhs assemble((g + c)*v*dx), adjoint rhs assemble((uhat - u)*v*dx) (all-time) or terminal condition
+    uhat_T - u(T) (final-time).  ``wind(x, y) -> (wx, wy)`` as in the scripts' ``velocity``."""
+
+    def __init__(self, mesh, num_steps, dt, wind, eps=1e-3, batch=1, device_id=0, order=_lib.ORDER_FENICS):
+        super().__init__(mesh, num_steps, dt, eps=eps, drift=(0.0, 0.0), rot_scale=1.0, batch=batch,
+                         device_id=device_id, order=order, wind=wind)
+        self._zero_c = self.ctx.zeros(self.tlen)     # no drift control: the control enters through the source
+
+    def state(self, src: DeviceArray, u: DeviceArray, batch=None):
+        """advection_FCT_PDECO_alltime_exact.py:236-253 (src = g + c, both trajectories)"""
+        self.forward(self._zero_c, u, batch=batch, c_shared=True, src=src)
+
+    def adjoint_state(self, u, uhat, p, optim="alltime", batch=None):
+        """:259-274 (all-time) / advection_FCT_PDECO_finaltime.py (final-time)"""
+        self.adjoint(self._zero_c, u, uhat, p, optim, batch=batch, c_shared=True)
+
+    def solve_state(self, src, uk):
+        s, u = self.ctx.array(src), self.ctx.array(uk)
+        try:
+            self.state(s, u, batch=1)
+            u.download(uk)
+        finally:
+            s.free()
+            u.free()
+        return uk
+
+    def solve_adjoint_state(self, uk, uhat, pk, optim="alltime"):
+        u, uh, p = self.ctx.array(uk), self.ctx.array(uhat), self.ctx.zeros(self.tlen)
+        try:
+            self.adjoint_state(u, uh, p, optim, batch=1)
+            p.download(pk)
+        finally:
+            for a in (u, uh, p):
+                a.free()
+        return pk
 
 
 def pgd_solidbody_finaltime(prob: SolidBodyDrift, u0, uhat_T, c0, beta, c_lower, c_upper, iters,

@@ -183,6 +183,12 @@ int femfct_drift_gradient_rhs(femfct_ctx* ctx, const double* c_dev, const double
 int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
                              double* u_traj, int32_t num_steps, double dt, double eps, double rot_scale,
                              double bx, double by, int32_t batch);
+/* the same sweep with a source term: rhs_{n+1} = assemble(src_{n+1}*v*dx) with src a trajectory, e.g. g + c of the
+ * linear source-control problems (advection_FCT_PDECO_alltime_exact.py:249-253, A_u = A - eps*Ad: pass the
+ * convection matrix as Arot_ell, rot_scale = 1 and a zero control).  src_traj NULL: no source. */
+int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
+                                 const double* src_traj, double* u_traj, int32_t num_steps, double dt, double eps,
+                                 double rot_scale, double bx, double by, int32_t batch);
 /* adjoint sweep: advection_solidbody_FCT_PDECO_finaltime.py:200-221 (alltime = 0: uhat is n doubles
  * per batch member, p(T) = uhat - u(T), zero rhs) and advection_solidbody_FCT_PDECO_alltime.py:232-259
  * (alltime = 1: uhat is a trajectory, p(T) = 0, rhs = assemble((uhat_n - u_n)*v*dx)) */

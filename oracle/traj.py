@@ -321,3 +321,70 @@ def solidbody_descent_direction(sb: SolidBody, ck, uk, pk, beta, nodes, num_step
         rhs = -(beta * (M @ ck[start:end]) + sb.asm.drift_gradient(pk[start:end], uk[start:end], sb.drift))
         dk[start:end] = chebsi(rhs, M, Md, 20, 0.5, 2)
     return dk
+
+
+# ---------------------------------------------------------------------------
+# linear advection-diffusion with a distributed source control and a manufactured solution
+#   advection_FCT_PDECO_alltime_exact.py (config C1's parameter set)
+# ---------------------------------------------------------------------------
+def exact_velocity(x, y):
+    """advection_FCT_PDECO_alltime_exact.py:132-135 (unit square)."""
+    return 2 * (y - 0.5) * x * (1 - x), -2 * (x - 0.5) * y * (1 - y)
+
+
+class LinearSource:
+    """Matrices of advection_FCT_PDECO_alltime_exact.py:160-176: A_u = A - eps*Ad, A_p = -A - eps*Ad."""
+
+    def __init__(self, asm, eps=1e-3, wind=exact_velocity):
+        self.asm = asm
+        self.cm = _common(asm)
+        self.eps = eps
+        self.A = asm.convection(wind)
+        self.A_u = self.A - eps * self.cm.Ad
+        self.A_p = -self.A - eps * self.cm.Ad
+
+
+def linear_forward(ls: LinearSource, src, uk, nodes, num_steps, dt):
+    """:240-253: u_rhs = assemble((g_np1 + c_np1)*v*dx) = M (g + c)_{n+1}; FCT_alg(A_u, ...) (old sign).
+    ``src`` = g + c as a trajectory."""
+    uk[nodes:] = np.zeros(num_steps * nodes)
+    for i in range(1, num_steps + 1):
+        start, end = i * nodes, (i + 1) * nodes
+        rhs = ls.cm.M @ src[start:end]
+        uk[start:end] = ls.cm.fct(-ls.A_u, rhs, uk[start - nodes:start], dt)
+    return uk
+
+
+def linear_adjoint(ls: LinearSource, uk, uhat, pk, nodes, num_steps, dt):
+    """:259-274: p(T) = 0, p_rhs = assemble((uhat_n - u_n)*v*dx), FCT_alg(A_p, ...)."""
+    pk[:] = 0.0
+    for i in reversed(range(0, num_steps)):
+        start, end = i * nodes, (i + 1) * nodes
+        rhs = ls.cm.M @ (uhat[start:end] - uk[start:end])
+        pk[start:end] = ls.cm.fct(-ls.A_p, rhs, pk[end:end + nodes], dt)
+    return pk
+
+
+def exact_fields(t, X, Y, T=1.0, beta=1e-3, c_lower=0.0, c_upper=0.5, e1=0.2, e2=0.3, k1=1, k2=1, eps=1e-3):
+    """uex, pex, cex, gex, uhatex of advection_FCT_PDECO_alltime_exact.py:77-128 at time t (inputs of the
+    manufactured problem; X, Y = meshgrid of np.arange(a1, a2+dx, dx))."""
+    pi = np.pi
+    sx, sy, cx, cy = np.sin(k1 * pi * X), np.sin(k1 * pi * Y), np.cos(k1 * pi * X), np.cos(k1 * pi * Y)
+    u = np.exp(e1 * t) * (sx * sy) ** 2
+    amp = np.exp(e2 * T) - np.exp(e2 * t)
+    sx2, sy2, cx2, cy2 = np.sin(k2 * pi * X), np.sin(k2 * pi * Y), np.cos(k2 * pi * X), np.cos(k2 * pi * Y)
+    p = amp * (sx2 * sy2) ** 2
+    c = np.clip(1 / beta * p, c_lower, c_upper)
+    wx, wy = exact_velocity(X, Y)
+    dudx = 2 * k1 * pi * np.exp(e1 * t) * sx * cx * sy ** 2
+    dudy = 2 * k1 * pi * np.exp(e1 * t) * sx ** 2 * sy * cy
+    du2dx2 = 2 * (pi * k1) ** 2 * np.exp(e1 * t) * np.cos(2 * k1 * pi * X) * sy ** 2
+    du2dy2 = 2 * (pi * k1) ** 2 * np.exp(e1 * t) * sx ** 2 * np.cos(2 * k1 * pi * Y)
+    g = e1 * u - eps * (du2dx2 + du2dy2) + wx * dudx + wy * dudy - c
+    dpdt = -e2 * np.exp(e2 * t) * (sx2 * sy2) ** 2
+    dpdx = 2 * k2 * pi * amp * sx2 * cx2 * sy2 ** 2
+    dpdy = 2 * k2 * pi * amp * sx2 ** 2 * sy2 * cy2
+    dp2dx2 = 2 * (pi * k2) ** 2 * amp * np.cos(2 * k2 * pi * X) * sy2 ** 2
+    dp2dy2 = 2 * (pi * k2) ** 2 * amp * sx2 ** 2 * np.cos(2 * k2 * pi * Y)
+    uhat = -dpdt - eps * (dp2dx2 + dp2dy2) - wx * dpdx - wy * dpdy + u
+    return dict(u=u, p=p, c=c, g=g, uhat=uhat)
