@@ -220,6 +220,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_BUILD")) ctx->fuse_build = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_PREASSEMBLE")) ctx->preassemble = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_PREASSEMBLE_MAX_GB")) ctx->preassemble_max_bytes = atof(e) * 1024.0 * 1024.0 * 1024.0;
+    if (const char* e = getenv("FEMFCT_WG_SLOTS")) ctx->wg_slots = std::max(1, atoi(e));
     if (const char* e = getenv("FEMFCT_DEEP_HALO")) ctx->deep_halo = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_FLUX")) ctx->fuse_flux = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;

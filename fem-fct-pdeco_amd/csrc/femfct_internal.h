@@ -72,6 +72,7 @@ struct femfct_ctx {
     int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always
     bool fuse_end = true;       // log + level advance done by the last workgroup of the step's final kernel
     bool fuse_build = true;     // low-order operator construction inside the first tile-Jacobi launch (small grids)
+    int wg_slots = 256;         // workgroups that run at once without queueing: bound for the deep-halo / fused-tail choices
     bool deep_halo = true;      // Jacobi halos 11..13 while every tile gets its own CU (fewer launches)
     bool fuse_flux = true;      // last Chebyshev iterations + flux + limiter in one tile launch (small grids)
     bool fuse_dudt = true;      // du/dt rhs + first Chebyshev iterations in one tile launch (small grids)

@@ -883,7 +883,7 @@ k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double*
 bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch) {
     if (!ctx->fuse_flux || ctx->N > 512) return false;
     const int t = (ctx->N + 7) / 8;
-    return (int64_t)t * t * batch <= 256;
+    return (int64_t)t * t * batch <= ctx->wg_slots;
 }
 
 int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old,
@@ -950,7 +950,7 @@ bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials, i
             int best = 1 << 30;
             for (int h = 8; h <= TILE_HMAX; ++h) {
                 const int T = TILE_L - 2 * h, t = (ctx->N + T - 1) / T;
-                if (h > 10 && (!ctx->deep_halo || (int64_t)t * t * batch > 256)) break;
+                if (h > 10 && (!ctx->deep_halo || (int64_t)t * t * batch > ctx->wg_slots)) break;
                 int launches = (budget + h - 1) / h;
                 if (launches < best) { best = launches; H = h; }
             }
