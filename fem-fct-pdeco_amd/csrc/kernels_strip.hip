@@ -1462,19 +1462,20 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     double* xout = ((launch & 1) ? xa_ : xb_) + voff;
     const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
     Strip4Node g[4];
-    double lv[4][W - 1], dg[4], rdg[4], bv[4], x[4];
+    // rows pre-scaled by 1 / l_ii: x_new = bs - sum ls * x_nb;  residual of the input iterate = l_ii |x_new - x|
+    double lv[4][W - 1], dg[4], bv[4], x[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         g[r] = strip4_node(N, r);
-        dg[r] = 1.0; rdg[r] = 1.0; bv[r] = 0.0; x[r] = 0.0;
+        dg[r] = 1.0; bv[r] = 0.0; x[r] = 0.0;
 #pragma unroll
         for (int s = 0; s < W - 1; ++s) lv[r][s] = 0.0;
         if (g[r].inside) {
             dg[r] = L[g[r].i];
-            rdg[r] = 1.0 / dg[r];
+            const double rdg = 1.0 / dg[r];
 #pragma unroll
-            for (int s = 1; s < W; ++s) lv[r][s - 1] = L[(int64_t)s * n + g[r].i];
-            bv[r] = b_[voff + g[r].i];
+            for (int s = 1; s < W; ++s) lv[r][s - 1] = L[(int64_t)s * n + g[r].i] * rdg;
+            bv[r] = b_[voff + g[r].i] * rdg;
             x[r] = xin[g[r].i];
         }
     }
@@ -1495,8 +1496,8 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
 #pragma unroll
             for (int s = 0; s < W - 1; ++s) acc = fma(-lv[r][s], STRIP4_NB(x, above, below, r, s), acc);
             if (k < g[r].kvalid) {
-                if (k == K - 1 && g[r].owned) rmax = fmax(rmax, fabs(acc - dg[r] * x[r]));
-                xn[r] = acc * rdg[r];
+                if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
+                xn[r] = acc;
             }
         }
 #pragma unroll
@@ -1526,19 +1527,21 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
     const int64_t voff = (int64_t)blockIdx.z * n;
     const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
     Strip4Node g[4];
-    double mv[4][W - 1], md[4], rmd[4], bv[4], ym[4], yo[4];
+    // rows pre-scaled by 1 / (md_scale * m_ii): z = bs - ym / md_scale - sum ms * y_nb  (two registers per node
+    // fewer than keeping m_ii and its reciprocal: no scratch spills at 128 VGPRs)
+    const double inv_scale = 1.0 / md_scale;
+    double mv[4][W - 1], bv[4], ym[4], yo[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         g[r] = strip4_node(N, r);
-        md[r] = 1.0; rmd[r] = 1.0; bv[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0;
+        bv[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0;
 #pragma unroll
         for (int s = 0; s < W - 1; ++s) mv[r][s] = 0.0;
         if (g[r].inside) {
-            md[r] = M[g[r].i];
-            rmd[r] = 1.0 / (md_scale * md[r]);
+            const double rmd = 1.0 / (md_scale * M[g[r].i]);
 #pragma unroll
-            for (int s = 1; s < W; ++s) mv[r][s - 1] = M[(int64_t)s * n + g[r].i];
-            bv[r] = b_[voff + g[r].i];
+            for (int s = 1; s < W; ++s) mv[r][s - 1] = M[(int64_t)s * n + g[r].i] * rmd;
+            bv[r] = b_[voff + g[r].i] * rmd;
             if (ymid_) ym[r] = ymid_[voff + g[r].i];
             if (yold_) yo[r] = yold_[voff + g[r].i];
         }
@@ -1556,13 +1559,10 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             yn[r] = ym[r];
-            double acc = md[r] * ym[r];
+            double z = fma(-inv_scale, ym[r], bv[r]);
 #pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc = fma(mv[r][s], STRIP4_NB(ym, above, below, r, s), acc);
-            if (k < g[r].kvalid) {
-                const double z = (bv[r] - acc) * rmd[r];
-                yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
-            }
+            for (int s = 0; s < W - 1; ++s) z = fma(-mv[r][s], STRIP4_NB(ym, above, below, r, s), z);
+            if (k < g[r].kvalid) yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
