@@ -22,13 +22,13 @@ struct WMassSpec {
     int64_t f1_bs = 0, f2_bs = 0;
 };
 
-// out_i = s0*(M mx)_i + s1 * int (k0 + k1*p1 + k2*q1*q2*q3) phi_i + s2*(da_i - db_i)
+// out_i = s0*(M mx)_i + s1 * int (k0 + k1*p1 + k2*q1*q2*q3) phi_i + s2*(da_i - db_i) + s3*(M (ea - eb))_i
 struct LoadSpec {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, k0 = 0.0, k1 = 0.0, k2 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, k0 = 0.0, k1 = 0.0, k2 = 0.0;
     VecRef mx{nullptr, nullptr, 0, 0}, p1{nullptr, nullptr, 0, 0}, q1{nullptr, nullptr, 0, 0},
         q2{nullptr, nullptr, 0, 0}, q3{nullptr, nullptr, 0, 0}, da{nullptr, nullptr, 0, 0},
-        db{nullptr, nullptr, 0, 0};
-    int64_t mx_bs = 0, p1_bs = 0, q1_bs = 0, q2_bs = 0, q3_bs = 0, da_bs = 0, db_bs = 0;
+        db{nullptr, nullptr, 0, 0}, ea{nullptr, nullptr, 0, 0}, eb{nullptr, nullptr, 0, 0};
+    int64_t mx_bs = 0, p1_bs = 0, q1_bs = 0, q2_bs = 0, q3_bs = 0, da_bs = 0, db_bs = 0, ea_bs = 0, eb_bs = 0;
 };
 
 MeshArgs femfct_mesh_args(const femfct_ctx* ctx);

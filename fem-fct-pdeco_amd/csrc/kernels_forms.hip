@@ -90,8 +90,9 @@ __global__ void k_weighted_mass(MeshArgs m, WMassSpec sp, double* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------
-// out_i = s0*(M x)_i + s1 * int (k0 + k1*p1 + k2*q1*q2*q3) phi_i + s2*(da_i - db_i)
-// (q3 may be absent = 1).  The raw nodal difference reproduces helpers.py:1506-1507,1533-1534.
+// out_i = s0*(M x)_i + s1 * int (k0 + k1*p1 + k2*q1*q2*q3) phi_i + s2*(da_i - db_i) + s3*(M (ea - eb))_i
+// (q3 may be absent = 1).  The raw nodal difference reproduces helpers.py:1506-1507,1533-1534; the
+// mass-weighted one is assemble((ea_h - eb_h)*w*dx) (Schnak_FCT_PDECO_alltime.py:268,278).
 // ---------------------------------------------------------------------------
 __global__ void k_load(MeshArgs m, LoadSpec sp, double* __restrict__ out_) {
     const int bz = blockIdx.y, n = m.n;
@@ -102,6 +103,8 @@ __global__ void k_load(MeshArgs m, LoadSpec sp, double* __restrict__ out_) {
     const double* q3 = bptr(sp.q3, sp.q3_bs, bz);
     const double* da = bptr(sp.da, sp.da_bs, bz);
     const double* db = bptr(sp.db, sp.db_bs, bz);
+    const double* ea = bptr(sp.ea, sp.ea_bs, bz);
+    const double* eb = bptr(sp.eb, sp.eb_bs, bz);
     double* out = out_ + (int64_t)bz * n;
     const double area = 0.5 * m.h * m.h;
     RowRange rr = block_rows(n);
@@ -142,6 +145,16 @@ __global__ void k_load(MeshArgs m, LoadSpec sp, double* __restrict__ out_) {
             res += sp.s1 * ld;
         }
         if (da && sp.s2 != 0.0) res += sp.s2 * (da[i] - (db ? db[i] : 0.0));
+        if (ea && sp.s3 != 0.0) {
+            double acc = m.M[i] * (ea[i] - (eb ? eb[i] : 0.0));
+#pragma unroll
+            for (int s = 1; s < STENCIL_W; ++s) {
+                int64_t idx = (int64_t)s * n + i;
+                int j = m.cols[idx];
+                acc += m.M[idx] * (ea[j] - (eb ? eb[j] : 0.0));
+            }
+            res += sp.s3 * acc;
+        }
         out[i] = res;
     }
 }

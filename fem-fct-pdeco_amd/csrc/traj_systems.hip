@@ -244,9 +244,12 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
 }
 
 // helpers.py:599-698.  AwT_ell = assemble_sparse(dot(wind,grad(u))*w*dx) = transpose of Aw.
+// alltime != 0 (no HEAD counterpart in helpers.py; structure of the inline loop Schnak_FCT_PDECO_alltime.py:204-284
+// with the HEAD operators): uhat/vhat are trajectories, p(T) = q(T) = 0, the q right-hand side gains
+// dt*assemble((vhat_n - v_n)*w*dx) (:268) and the p right-hand side assemble((uhat_n - u_n)*w*dx) (:278).
 int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* u_traj, const double* v_traj,
                           const double* uhat_T, const double* vhat_T, double* p_traj, double* q_traj,
-                          int32_t num_steps, double dt, const double* par, int32_t batch) {
+                          int32_t num_steps, double dt, const double* par, int32_t alltime, int32_t batch) {
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, AwT_ell && u_traj && v_traj && uhat_T && vhat_T && p_traj && q_traj && par, "null argument");
@@ -261,6 +264,13 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
         WMassSpec ws;
         ws.alpha = 1.0; ws.gamma = dt; ws.base = ctx->d_trBase2;
         femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
+        if (alltime) {
+            for (int32_t b = 0; b < batch; ++b) {
+                HIP_TRY(ctx, hipMemsetAsync(p_traj + b * ts + (int64_t)num_steps * n, 0, sizeof(double) * n, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(q_traj + b * ts + (int64_t)num_steps * n, 0, sizeof(double) * n, ctx->stream));
+            }
+            return FEMFCT_OK;
+        }
         terminal_diff(ctx, uhat_T, u_traj, p_traj, num_steps, batch);
         return terminal_diff(ctx, vhat_T, v_traj, q_traj, num_steps, batch);
     };
@@ -268,7 +278,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
         auto key = KEY((uint64_t)13, key_bits(AwT_ell), key_bits(u_traj), key_bits(v_traj), key_bits(uhat_T),
                        key_bits(vhat_T), key_bits(p_traj), key_bits(q_traj), key_bits(num_steps), key_bits(dt),
                        key_bits(Du), key_bits(Dv), key_bits(gam), key_bits(om1), key_bits(om2), key_bits(batch),
-                       key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
+                       key_bits(alltime), key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
                        key_bits((int32_t)femfct_species_cheb(ctx, 13)));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // q first (helpers.py:683-686): Mat_q = M + dt*(Dv*Ad - omega2*A' + gamma*M_u2(u_n))
@@ -279,6 +289,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
             LoadSpec lq;  // M@q_{n+1} + dt*assemble(gamma*p_{n+1}*u_n^2*w*dx)
             lq.s0 = 1.0; lq.mx = L(q_traj, 1); lq.mx_bs = ts; lq.s1 = dt; lq.k2 = gam;
             lq.q1 = L(p_traj, 1); lq.q2 = L(u_traj, 0); lq.q3 = L(u_traj, 0); lq.q1_bs = lq.q2_bs = lq.q3_bs = ts;
+            if (alltime) { lq.s3 = dt; lq.ea = L(vhat_T, 0); lq.eb = L(v_traj, 0); lq.ea_bs = lq.eb_bs = ts; }
             femfct_enqueue_load(ctx, lq, ctx->d_trRhs2, batch);
             int r = femfct_enqueue_species_solve(ctx, 13, ctx->d_trMat, 0, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget, dt * Dv);
             if (r != FEMFCT_OK) return r;
@@ -289,6 +300,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
             LoadSpec lp;
             lp.s1 = 1.0; lp.k2 = -2.0 * gam; lp.q1 = L(u_traj, 0); lp.q2 = L(v_traj, 0); lp.q3 = L(q_traj, 0);
             lp.q1_bs = lp.q2_bs = lp.q3_bs = ts;
+            if (alltime) { lp.s3 = 1.0; lp.ea = L(uhat_T, 0); lp.eb = L(u_traj, 0); lp.ea_bs = lp.eb_bs = ts; }
             femfct_enqueue_load(ctx, lp, ctx->d_trRhs, batch);
             femfct_request_fused_end(ctx, -1, true);
             r = femfct_enqueue_step_ref(ctx, ctx->d_trA, ctx->d_trN, 0, make_ref(ctx->d_trRhs), n, L(p_traj, 1), ts, dt,

@@ -346,10 +346,11 @@ class Context:
         check(self.handle, lib.femfct_schnak_forward(self.handle, dptr(Aw), dptr(c_level), dptr(u), dptr(v),
                                                      int(num_steps), float(dt), _host_ptr(par), float(rescaling), int(batch)))
 
-    def schnak_adjoint(self, AwT, u, v, uhat_T, vhat_T, p, q, num_steps, dt, par, batch=1):
+    def schnak_adjoint(self, AwT, u, v, uhat_T, vhat_T, p, q, num_steps, dt, par, batch=1, alltime=False):
         par = _as_f64(par)
         check(self.handle, lib.femfct_schnak_adjoint(self.handle, dptr(AwT), dptr(u), dptr(v), dptr(uhat_T), dptr(vhat_T),
-                                                     dptr(p), dptr(q), int(num_steps), float(dt), _host_ptr(par), int(batch)))
+                                                     dptr(p), dptr(q), int(num_steps), float(dt), _host_ptr(par),
+                                                     int(bool(alltime)), int(batch)))
 
     def chtxs_forward(self, c_level, u, v, num_steps, dt, par, rescaling=0.1, batch=1):
         par = _as_f64(par)

@@ -122,7 +122,8 @@ class SystemPDECO:
         if self.problem == "nonlinear":
             self.ctx.nonlinear_adjoint(self.Aw, u, tg[0], p, self.Nt, self.dt, self.eps)
         elif self.problem == "schnak":
-            self.ctx.schnak_adjoint(self.AwT, u, v, tg[0], tg[1], p, q, self.Nt, self.dt, self.par)
+            self.ctx.schnak_adjoint(self.AwT, u, v, tg[0], tg[1], p, q, self.Nt, self.dt, self.par,
+                                    alltime=self.P["optim"] == "alltime")
         else:
             self.ctx.chtxs_adjoint(u, v, tg[0], tg[1], p, q, c, self.Nt, self.dt, self.par, self.P["rescaling"],
                                    self.P["optim"] == "alltime")

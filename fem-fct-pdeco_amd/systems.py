@@ -222,15 +222,21 @@ def solve_schnak_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighb
     return var1, var2
 
 
-def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, V, nodes, num_steps, dt, dof_neighbors):
-    """helpers.py:599-698."""
+def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, V, nodes, num_steps, dt, dof_neighbors,
+                                optim="finaltime"):
+    """helpers.py:599-698 (``optim="finaltime"``, the reference's signature and behaviour).
+    ``optim="alltime"`` (extension, structure of Schnak_FCT_PDECO_alltime.py:204-284): the targets are
+    trajectories, p(T) = q(T) = 0 and both equations carry the assembled misfit."""
+    if optim not in ("alltime", "finaltime"):
+        raise ValueError(f"Invalid value for 'optim': '{optim}'. Must be one of ['alltime', 'finaltime'].")
     S = _system(V)
     par, wind = _schnak_par()
     _, AwT = S.convection(wind, "schnak")
     B = _Bufs(S)
     try:
         p, q = B.up(pk), B.up(qk)
-        S.ctx.schnak_adjoint(AwT, B.up(uk), B.up(vk), B.up(uhat_T), B.up(vhat_T), p, q, num_steps, dt, par)
+        S.ctx.schnak_adjoint(AwT, B.up(uk), B.up(vk), B.up(uhat_T), B.up(vhat_T), p, q, num_steps, dt, par,
+                             alltime=optim == "alltime")
         B.down(p, pk)
         B.down(q, qk)
     finally:

@@ -261,10 +261,13 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
 int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c_level, double* u_traj,
                           double* v_traj, int32_t num_steps, double dt, const double* par, double rescaling,
                           int32_t batch);
-/* solve_adjoint_schnak_system (helpers.py:599-698); AwT_ell = femfct_ell_transpose(Aw_ell) */
+/* solve_adjoint_schnak_system (helpers.py:599-698); AwT_ell = femfct_ell_transpose(Aw_ell).
+ * alltime = 0: the reference's final-time problem (uhat_T, vhat_T: n doubles per batch member).
+ * alltime = 1: all-time misfit (targets are trajectories, p(T) = q(T) = 0, misfit loads in both equations as
+ * in the inline loop of Schnak_FCT_PDECO_alltime.py:204-284; helpers.py has no such variant). */
 int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* u_traj, const double* v_traj,
                           const double* uhat_T, const double* vhat_T, double* p_traj, double* q_traj,
-                          int32_t num_steps, double dt, const double* par, int32_t batch);
+                          int32_t num_steps, double dt, const double* par, int32_t alltime, int32_t batch);
 /* solve_chtxs_system (helpers.py:1250-1385, non-generation mode); par = {delta, Dm, Df, chi, eta} */
 int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj, double* v_traj,
                          int32_t num_steps, double dt, const double* par, double rescaling, int32_t batch);

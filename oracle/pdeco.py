@@ -65,7 +65,8 @@ def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, **ov
         if problem == "nonlinear":
             return traj.solve_adjoint_nonlinear_equation(uk, targets[0], pk, T, asm, nodes, num_steps, dt), None
         if problem == "schnak":
-            return traj.solve_adjoint_schnak_system(uk, vk, targets[0], targets[1], pk, qk, T, asm, nodes, num_steps, dt)
+            return traj.solve_adjoint_schnak_system(uk, vk, targets[0], targets[1], pk, qk, T, asm, nodes, num_steps, dt,
+                                                    None, optim)
         return traj.solve_adjoint_chtxs_system(uk, vk, targets[0], targets[1], pk, qk, ck, T, asm, nodes, num_steps,
                                                dt, None, optim, rescaling=r)
 

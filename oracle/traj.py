@@ -168,13 +168,20 @@ def solve_schnak_system(control, var1, var2, asm, nodes, num_steps, dt, dof_neig
 
 
 def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, asm, nodes, num_steps, dt,
-                                dof_neighbors=None):
-    """helpers.py:599-698."""
+                                dof_neighbors=None, optim="finaltime"):
+    """helpers.py:599-698 (optim="finaltime").  optim="alltime" is an extension without a HEAD counterpart:
+    zero terminal conditions and the misfit loads of the inline loop Schnak_FCT_PDECO_alltime.py:268
+    (rhs_q += assemble((vhat_n - v_n)*w*dx)) and :278 (rhs_p += assemble((uhat_n - u_n)*w*dx)), alpha = 1."""
     cm = _common(asm)
     P = schnak_params()
     Du, Dv, gamma, om1, om2 = P["Du"], P["Dv"], P["gamma"], P["omega1"], P["omega2"]
-    pk[num_steps * nodes:] = uhat_T - uk[num_steps * nodes:]
-    qk[num_steps * nodes:] = vhat_T - vk[num_steps * nodes:]
+    alltime = optim == "alltime"
+    if alltime:
+        pk[num_steps * nodes:] = 0.0
+        qk[num_steps * nodes:] = 0.0
+    else:
+        pk[num_steps * nodes:] = uhat_T - uk[num_steps * nodes:]
+        qk[num_steps * nodes:] = vhat_T - vk[num_steps * nodes:]
     # dot(wind, grad(u))*w*dx is the transpose of dot(wind, grad(w))*u*dx (helpers.py:681)
     A = asm.convection(schnak_wind).T.tocsr()
     for i in reversed(range(0, num_steps)):
@@ -185,12 +192,16 @@ def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, asm, nodes, n
         v_n = vk[start:end]
         M_u2 = asm.weighted_mass(lambda at: at(u_n) ** 2)
         rhs_q = asm.load(lambda at: gamma * at(p_np1) * at(u_n) ** 2)
+        if alltime:
+            rhs_q = rhs_q + cm.M @ (vhat_T[start:end] - v_n)
         Mat_q = cm.M + dt * (Dv * cm.Ad - om2 * A + gamma * M_u2)
         qk[start:end] = spsolve(Mat_q.tocsc(), cm.M @ q_np1 + dt * rhs_q)
         q_n = qk[start:end]
         Mat_p = Du * cm.Ad - om1 * A
         M_uv = asm.weighted_mass(lambda at: at(u_n) * at(v_n))
         rhs_p = asm.load(lambda at: -2 * gamma * at(u_n) * at(v_n) * at(q_n))
+        if alltime:
+            rhs_p = rhs_p + cm.M @ (uhat_T[start:end] - u_n)
         Mat_rhs = gamma * cm.M - 2 * gamma * M_uv
         pk[start:end] = cm.fct(Mat_p, rhs_p, p_np1, dt, non_flux_mat=Mat_rhs)
     return pk, qk

@@ -20,7 +20,7 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _setup(hp, problem, nc, Nt, dt):
+def _setup(hp, problem, nc, Nt, dt, optim="finaltime"):
     from oracle.mesh import SquareMesh
     from oracle.assembly import P1Assembler
     from oracle import traj as otraj
@@ -40,7 +40,7 @@ def _setup(hp, problem, nc, Nt, dt):
         u0, v0 = hp.schnak_sys_IC(0, 1, 1.0 / nc, n, V.vertex_to_dof)
         ic = (u0, v0)
         ut, vt = otraj.solve_schnak_system(np.full(tl, 0.1), z(u0), z(v0), asm, n, Nt, dt)
-        targets = (ut[Nt * n:].copy(), vt[Nt * n:].copy())
+        targets = (ut[Nt * n:].copy(), vt[Nt * n:].copy()) if optim == "finaltime" else (ut.copy(), vt.copy())
     else:
         u0 = 1.5 + 0.1 * (0.5 - rng.random(n))
         ic = (u0, u0.copy())
@@ -54,11 +54,12 @@ def _setup(hp, problem, nc, Nt, dt):
     ("nonlinear", 10, 2e-3, dict(max_iter_GD=4)),
     ("schnak", 8, 1e-3, dict(max_iter_GD=3)),                        # line searches hit max_iter: restore path
     ("schnak", 8, 1e-3, dict(max_iter_GD=3, max_iter_armijo=14)),
+    ("schnak", 8, 1e-3, dict(max_iter_GD=3, max_iter_armijo=14, optim="alltime")),     # config C3's misfit
     ("chtxs", 8, 5e-4, dict(max_iter_GD=3, max_iter_armijo=8)),
 ])
 def test_pgd_loop_matches_oracle_loop(hp, problem, Nt, dt, opts, speculative):
     from oracle import pdeco as opdeco
-    asm, V, ic, targets = _setup(hp, problem, 12, Nt, dt)
+    asm, V, ic, targets = _setup(hp, problem, 12, Nt, dt, opts.get("optim", "finaltime"))
     ref = opdeco.projected_gradient_descent(problem, asm, asm.mass(), ic, targets, Nt, dt, **opts)
     got = hp.projected_gradient_descent(problem, V, ic, targets, Nt, dt, speculative=speculative, **opts)
     assert got["it"] == ref["it"] and got["restored"] == ref["restored"]

@@ -122,6 +122,16 @@ def test_schnak_forward_adjoint_vs_oracle(hp):
     po, qo = otraj.solve_adjoint_schnak_system(uo, vo, uhat, vhat, np.zeros_like(uo), np.zeros_like(uo), Nt * dt, asm, n, Nt, dt)
     pg, qg = hp.solve_adjoint_schnak_system(ug, vg, uhat, vhat, np.zeros_like(ug), np.zeros_like(ug), Nt * dt, V, n, Nt, dt, None)
     assert rel(pg, po) < 1e-8 and rel(qg, qo) < 1e-8
+    # all-time misfit (extension; config C3): trajectory targets, zero terminal conditions
+    uh, vh = 0.9 * uo + 0.01, 1.1 * vo
+    po, qo = otraj.solve_adjoint_schnak_system(uo, vo, uh, vh, np.zeros_like(uo), np.zeros_like(uo), Nt * dt, asm, n, Nt, dt,
+                                               None, "alltime")
+    pg, qg = hp.solve_adjoint_schnak_system(ug, vg, uh, vh, np.ones_like(ug), np.ones_like(ug), Nt * dt, V, n, Nt, dt, None,
+                                            optim="alltime")
+    assert rel(pg, po) < 1e-8 and rel(qg, qo) < 1e-8
+    assert not pg[Nt * n:].any() and not qg[Nt * n:].any()
+    with pytest.raises(ValueError):
+        hp.solve_adjoint_schnak_system(ug, vg, uh, vh, pg, qg, Nt * dt, V, n, Nt, dt, None, optim="sometime")
 
 
 @pytest.mark.parametrize("optim", ["alltime", "finaltime"])
