@@ -1495,10 +1495,10 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
             double acc = bv[r];
 #pragma unroll
             for (int s = 0; s < W - 1; ++s) acc = fma(-lv[r][s], STRIP4_NB(x, above, below, r, s), acc);
-            if (k < g[r].kvalid) {
-                if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
-                xn[r] = acc;
-            }
+            // no validity guard: a node at distance d from the patch border is exact after k <= d sweeps whatever
+            // the nodes further out hold (they stay bounded: rows are diagonally dominant, outside rows are zero)
+            if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
+            xn[r] = acc;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = xn[r];
@@ -1562,7 +1562,7 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
             double z = fma(-inv_scale, ym[r], bv[r]);
 #pragma unroll
             for (int s = 0; s < W - 1; ++s) z = fma(-mv[r][s], STRIP4_NB(ym, above, below, r, s), z);
-            if (k < g[r].kvalid) yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
+            yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];     // no validity guard (see k_strip4_jacobi)
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
