@@ -677,6 +677,33 @@ struct EndArgs {
     unsigned* ticket;
 };
 
+// End of a time step folded into the step's last kernel: the workgroup that draws the last ticket copies the
+// per-step solver records into the trajectory log and advances the device-side time level.  Every workgroup
+// has resolved its level-dependent addresses before it draws a ticket, so moving the level is safe.
+__device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
+    if (!e.level) return;
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        is_last = (atomicAdd(e.ticket, 1u) == total - 1);
+    }
+    __syncthreads();
+    if (is_last) {
+        const int ord = e.level[1];
+        for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
+            e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
+            if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            e.level[0] += e.delta;
+            e.level[1] = ord + 1;
+            *e.ticket = 0u;
+        }
+    }
+}
+
 #define FL_H 2
 template <int FL_L>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
 __global__ void __launch_bounds__(FL_L * FL_L)
@@ -733,30 +760,7 @@ k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __re
         double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
         out[g.i] = ui + dt * fbar / mli;
     }
-    if (e.level) {
-        // every workgroup has resolved its level-dependent addresses before it draws a ticket, so the
-        // workgroup that draws the last one may move the level
-        __shared__ int is_last;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-            is_last = (atomicAdd(e.ticket, 1u) == total - 1);
-        }
-        __syncthreads();
-        if (is_last) {
-            const int ord = e.level[1];
-            for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
-                e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
-                if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                e.level[0] += e.delta;
-                e.level[1] = ord + 1;
-                *e.ticket = 0u;
-            }
-        }
-    }
+    step_end_by_last_workgroup(e);
 }
 
 }  // namespace
@@ -853,28 +857,7 @@ k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double*
         double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
         out[g.i] = ui + dt * fbar / mli;
     }
-    if (e.level) {
-        __shared__ int is_last;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-            is_last = (atomicAdd(e.ticket, 1u) == total - 1);
-        }
-        __syncthreads();
-        if (is_last) {
-            const int ord = e.level[1];
-            for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
-                e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
-                if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                e.level[0] += e.delta;
-                e.level[1] = ord + 1;
-                *e.ticket = 0u;
-            }
-        }
-    }
+    step_end_by_last_workgroup(e);
 }
 
 }  // namespace
