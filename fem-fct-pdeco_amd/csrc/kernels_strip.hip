@@ -21,7 +21,7 @@
 
 namespace {
 
-struct CheOmegas { double w[10]; };
+struct CheOmegas { double w[16]; };   // omegas of one launch (up to TILE_HMAX iterations)
 
 template <int RPT>
 __global__ void __launch_bounds__(STRIP_T)
@@ -1025,7 +1025,10 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
 #define TC(HH) hipLaunchKernelGGL((k_tile_cheb<HH>), dim3(pl.tiles, pl.tiles, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, \
                                   ctx->N, ctx->d_M, b, mid, old, omid, oold, k1 - k0, om, md_scale, io)
-        if (pl.H == 8) TC(8); else if (pl.H == 9) TC(9); else TC(10);
+        switch (pl.H) {
+            case 8: TC(8); break; case 9: TC(9); break; case 10: TC(10); break;
+            case 11: TC(11); break; case 12: TC(12); break; default: TC(13); break;
+        }
 #undef TC
         femfct_prof_end(ctx);
         mid = omid;
