@@ -119,6 +119,24 @@ __device__ __forceinline__ double block_reduce(double v, Op op, double identity,
     return r;
 }
 
+// Three reductions (max, max, min) with one barrier pair instead of three; smem must hold >= 96 doubles.
+__device__ __forceinline__ void block_reduce_max_max_min(double& a, double& b, double& c, double* smem) {
+    a = wave_reduce(a, OpMax());
+    b = wave_reduce(b, OpMax());
+    c = wave_reduce(c, OpMin());
+    const int nw = (blockDim.x + WAVE - 1) / WAVE;
+    if (nw == 1) return;
+    const int wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    __syncthreads();  // smem reuse across successive calls
+    if (lane == 0) { smem[wid] = a; smem[32 + wid] = b; smem[64 + wid] = c; }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0, rc = INFINITY;
+    for (int w = 0; w < nw; ++w) {   // fixed order: deterministic
+        ra = fmax(ra, smem[w]); rb = fmax(rb, smem[32 + w]); rc = fmin(rc, smem[64 + w]);
+    }
+    a = ra; b = rb; c = rc;
+}
+
 // Every block reduces the same `count` per-block partials in the same order, so
 // all blocks obtain a bitwise identical value without any atomics.
 template <class Op>

@@ -357,7 +357,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
               int g_build, double rel_tol, double* __restrict__ bigpart, double* __restrict__ partk, int bn_launch) {
     constexpr int W = 7;
     __shared__ double xs[2][TILE_L * TILE_LD];
-    __shared__ double smem[32];
+    __shared__ double smem[96];
     const int bz = blockIdx.z;
     StepCtl* ctl = ctl_ + bz;
     if (ctl->done) return;
@@ -365,10 +365,26 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
     double bnorm;
     // ||b||, min row sum: reduced from the partials of the kernel that built L (k_build_low before launch 0,
-    // or the fused k_tile_build_jacobi = launch 0 itself, then bn_launch = 1)
+    // or the fused k_tile_build_jacobi = launch 0 itself, then bn_launch = 1); launch >= 1 also tests the
+    // residual the previous launch left.  In the fused case all three come out of one reduction pass.
+    double rmax_prev = 0.0;
+    bool have_rmax = false;
     if (launch == bn_launch) {
-        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
-        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        double rsmin = INFINITY;
+        bnorm = 0.0;
+        if (!BIG && launch > 0 && g_build == nwg) {
+            const double* pr = p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS;
+            for (int k = threadIdx.x; k < nwg; k += blockDim.x) {
+                bnorm = fmax(bnorm, p[2 * FEMFCT_MAX_PARTIALS + k]);
+                rmax_prev = fmax(rmax_prev, pr[k]);
+                rsmin = fmin(rsmin, p[3 * FEMFCT_MAX_PARTIALS + k]);
+            }
+            block_reduce_max_max_min(bnorm, rmax_prev, rsmin, smem);
+            have_rmax = true;
+        } else {
+            bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+            rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        }
         if (wg == 0 && threadIdx.x == 0) {
             ctl->bnorm = bnorm;
             ctl->min_rowsum = rsmin;
@@ -378,8 +394,9 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
         bnorm = ctl->bnorm;
     }
     if (launch > 0) {
-        double rmax = BIG ? ctl->rs[(launch - 1) & 1]
-                          : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        double rmax = have_rmax ? rmax_prev
+                      : BIG   ? ctl->rs[(launch - 1) & 1]
+                              : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (wg == 0 && threadIdx.x == 0) {
                 ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
@@ -483,7 +500,7 @@ k_tile_build_jacobi(int n, int N, MatRef A_ref, const double* __restrict__ N_, i
     constexpr int W = 7;
     __shared__ double xs[2][TILE_L * TILE_LD];
     __shared__ double as[3][TILE_L * TILE_LD];
-    __shared__ double smem[32];
+    __shared__ double smem[96];
     const int bz = blockIdx.z;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
@@ -584,9 +601,7 @@ k_tile_build_jacobi(int n, int N, MatRef A_ref, const double* __restrict__ N_, i
         cur ^= 1;
     }
     if (g.owned) xb_[voff + g.i] = xs[cur][g.self];
-    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
-    bmax = block_reduce(bmax, OpMax(), 0.0, smem);
-    rsmin = block_reduce(rsmin, OpMin(), INFINITY, smem);
+    block_reduce_max_max_min(rmax, bmax, rsmin, smem);
     if (threadIdx.x == 0) {
         p[wg] = rmax;
         p[2 * FEMFCT_MAX_PARTIALS + wg] = bmax;
