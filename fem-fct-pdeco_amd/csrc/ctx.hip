@@ -171,7 +171,7 @@ int femfct_next_budget(const femfct_ctx* ctx, int worst, bool coarse) {
     // sweep of margin.  No margin otherwise: the halo depth is re-chosen from the budget, and a budget that
     // creeps up by one per sweep walks through 2 x 12, 2 x 13, 3 x 9, 3 x 10, ... launches for nothing.
     if (mode == 2) b = std::max(worst, 1) + ((coarse || !ctx->exact_iters) ? 0 : 1);
-    else if (mode == 1) b = ((std::max(worst, 1) + K - 1) / K) * K;        // whole launches
+    else if (mode == 1) b = std::max(worst, 1);   // whole launches are formed from the budget by the launch plan
     else b = std::max(8, worst + worst / 8 + 2);
     return std::min(ctx->max_iters, b);
 }

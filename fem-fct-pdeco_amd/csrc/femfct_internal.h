@@ -61,6 +61,7 @@ struct femfct_ctx {
     double rel_tol = 1e-13;
     int max_iters = 400;
     int sweep_budget = 48;      // adaptive: sweeps enqueued per step (stand-alone femfct_fct_step)
+    std::map<int, int> kind_good;   // last Jacobi budget that sufficed, per kind
     std::map<int, int> kind_fail;   // largest Jacobi budget known to be too small, per kind
     std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
@@ -209,9 +210,12 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
                                         bool fuse_end);
 int femfct_tile4_init(femfct_ctx* ctx);
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
-int femfct_tile4_tiles(const femfct_ctx* ctx);
+int femfct_tile4_tiles(const femfct_ctx* ctx, int H = 8);
+int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps);
+// launches and sweeps per launch the low-order solve of femfct_enqueue_step_mat will use for a budget
+bool femfct_jacobi_plan(const femfct_ctx* ctx, int budget, int batch, int* K, int* launches);
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch);
+                                int g_build, int32_t batch, int H = 8, int K = 8);
 int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
                               double* bufB0, double* bufB1, int32_t batch,

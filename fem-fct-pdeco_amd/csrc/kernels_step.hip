@@ -520,14 +520,15 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
         femfct_enqueue_kry_to_stepctl(ctx, (int)g.grid.x, batch);
         units = 0;
     } else if (tile4) {
-        const int t4 = femfct_tile4_tiles(ctx);
+        const int h4 = femfct_tile4_halo(ctx, budget);
+        const int t4 = femfct_tile4_tiles(ctx, h4);
         const bool big4 = (int64_t)t4 * t4 > FEMFCT_MAX_PARTIALS;
-        const int k4 = ctx->t4_k;       // sweeps per launch (8; fewer only as a measurement knob)
+        const int k4 = std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);   // sweeps per launch (t4_k < 8: measurement knob)
         units = (budget + k4 - 1) / k4;
         part_count = big4 ? -1 : t4 * t4;
         ipu = k4;
         for (int s = 0; s < units; ++s)
-            femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch);
+            femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch, h4, k4);
     } else if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
@@ -592,6 +593,19 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return FEMFCT_OK;
+}
+
+bool femfct_jacobi_plan(const femfct_ctx* ctx, int budget, int batch, int* K, int* launches) {
+    TilePlan tp;
+    if (!femfct_tile_plan(ctx, &tp, false, budget, batch)) return false;
+    if (femfct_tile4_wanted(ctx, batch)) {
+        const int h4 = femfct_tile4_halo(ctx, budget);
+        *K = std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);
+    } else {
+        *K = tp.K;
+    }
+    *launches = (budget + *K - 1) / *K;
+    return true;
 }
 
 int femfct_enqueue_step(femfct_ctx* ctx, const double* A, const double* N, int32_t nshared, const double* rhs,

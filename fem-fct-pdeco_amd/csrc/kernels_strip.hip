@@ -1397,20 +1397,16 @@ struct Strip4Node {
     bool inside, owned;
 };
 
-__device__ __forceinline__ Strip4Node strip4_node(int N, int r) {
+__device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H) {
     Strip4Node g;
+    const int T = T4_L - 2 * H;          // halo depth is a launch parameter (8..10): K <= H sweeps per launch
     const int lx = threadIdx.x & 63, ly = 4 * (threadIdx.x >> 6) + r;
-    const int x0 = blockIdx.x * T4_T - T4_H, y0 = blockIdx.y * T4_T - T4_H;
+    const int x0 = blockIdx.x * T - H, y0 = blockIdx.y * T - H;
     const int gx = x0 + lx, gy = y0 + ly;
     g.inside = gx >= 0 && gx < N && gy >= 0 && gy < N;
     g.i = g.inside ? gy * N + gx : 0;
-    g.owned = g.inside && lx >= T4_H && lx < T4_H + T4_T && ly >= T4_H && ly < T4_H + T4_T;
-    int kv = 1 << 20;
-    if (x0 > 0) kv = min(kv, lx);
-    if (x0 + T4_L - 1 < N - 1) kv = min(kv, T4_L - 1 - lx);
-    if (y0 > 0) kv = min(kv, ly);
-    if (y0 + T4_L - 1 < N - 1) kv = min(kv, T4_L - 1 - ly);
-    g.kvalid = g.inside ? kv : 0;
+    g.owned = g.inside && lx >= H && lx < H + T && ly >= H && ly < H + T;
+    g.kvalid = 0;                        // (unused: see the note on validity guards in k_strip4_jacobi)
     return g;
 }
 
@@ -1427,7 +1423,7 @@ template <int BIG>
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                 double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-                int g_build, double rel_tol, double* __restrict__ bigpart) {
+                int g_build, double rel_tol, double* __restrict__ bigpart, int H) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     __shared__ double smem[32];
@@ -1467,7 +1463,7 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     double lv[4][W - 1], dg[4], bv[4], x[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        g[r] = strip4_node(N, r);
+        g[r] = strip4_node(N, r, H);
         dg[r] = 1.0; bv[r] = 0.0; x[r] = 0.0;
 #pragma unroll
         for (int s = 0; s < W - 1; ++s) lv[r][s] = 0.0;
@@ -1517,7 +1513,7 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
               const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
-              CheOmegas om, double md_scale, ChebIO cio) {
+              CheOmegas om, double md_scale, ChebIO cio, int H) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     if (cio.mat) M = cio.mat + (int64_t)blockIdx.z * cio.mat_bs;
@@ -1534,7 +1530,7 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
     double mv[4][W - 1], bv[4], ym[4], yo[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        g[r] = strip4_node(N, r);
+        g[r] = strip4_node(N, r, H);
         bv[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0;
 #pragma unroll
         for (int s = 0; s < W - 1; ++s) mv[r][s] = 0.0;
@@ -1593,11 +1589,30 @@ bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch) {
     return (int64_t)ctx->n * batch >= 150000;   // measured crossover at n = 6561: batch ~ 24
 }
 
-int femfct_tile4_tiles(const femfct_ctx* ctx) { return (ctx->N + T4_T - 1) / T4_T; }
+int femfct_tile4_tiles(const femfct_ctx* ctx, int H) {
+    const int T = T4_L - 2 * H;
+    return (ctx->N + T - 1) / T;
+}
+
+// Halo depth (= sweeps per launch) of the 64-patch strip kernels for `sweeps` sweeps in a row.  Measured launch
+// model at n = 2049^2: ~106 us of matrix load + ~5.6 us per sweep with halo 8; both scale with the patch
+// redundancy (48 / (64 - 2H))^2.  E.g. 36 sweeps = 4 x 9, 19 Chebyshev iterations = 10 + 9.
+int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
+    if (!ctx->t4_dpp || ctx->t4_k != 8) return T4_H;   // LDS-image variant / measurement knob: fixed geometry
+    int best_h = T4_H;
+    double best = 1e300;
+    for (int h = T4_H; h <= 10; ++h) {
+        const double af = (48.0 / (T4_L - 2 * h)) * (48.0 / (T4_L - 2 * h));
+        const int launches = (sweeps + h - 1) / h;
+        const double cost = af * (106.0 * launches + 5.6 * sweeps);
+        if (cost < best - 1e-9) { best = cost; best_h = h; }
+    }
+    return best_h;
+}
 
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch) {
-    const int t = femfct_tile4_tiles(ctx);
+                                int g_build, int32_t batch, int H, int K) {
+    const int t = femfct_tile4_tiles(ctx, H);
     const bool big = (int64_t)t * t > FEMFCT_MAX_PARTIALS;
     dim3 grid(t, t, batch);
     const size_t lds = (size_t)2 * T4_BUF * 8;
@@ -1605,21 +1620,21 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     if (ctx->t4_dpp) {
         if (big) {
             hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, ctx->d_bigpart);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H);
             hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                                ctx->d_ctl, launch);
         } else {
             hipLaunchKernelGGL(k_strip4_jacobi<0>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, (double*)nullptr);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H);
         }
     } else if (big) {
         hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                           ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, ctx->d_bigpart);
+                           ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart);
         hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                            ctx->d_ctl, launch);
     } else {
         hipLaunchKernelGGL(k_tile4_jacobi<0>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                           ctx->d_ctl, launch, ctx->t4_k, g_build, ctx->rel_tol, (double*)nullptr);
+                           ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr);
     }
     femfct_prof_end(ctx);
     return FEMFCT_OK;
@@ -1631,13 +1646,14 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
     ChebIO io0{};
     if (io_in) io0 = *io_in;
     io0.mid_ref = make_ref(nullptr); io0.mid_bs = 0; io0.out_ref = make_ref(nullptr); io0.out_bs = 0;
-    const int t = femfct_tile4_tiles(ctx);
+    const int H = femfct_tile4_halo(ctx, k_last - k_first + 1);
+    const int t = femfct_tile4_tiles(ctx, H);
     const size_t lds = (size_t)3 * T4_BUF * 8;
     const double* mid = in_mid;
     const double* old = in_old;
     int which = 0;
-    for (int k0 = k_first; k0 <= k_last; k0 += T4_H) {
-        int k1 = std::min(k_last + 1, k0 + T4_H);
+    for (int k0 = k_first; k0 <= k_last; k0 += H) {
+        int k1 = std::min(k_last + 1, k0 + H);
         CheOmegas om;
         for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas ? omegas[k - 1] : 0.0;
         const bool last = (k1 == k_last + 1);
@@ -1650,7 +1666,7 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         femfct_prof_begin(ctx, KC_CHEB);
         if (ctx->t4_dpp)
             hipLaunchKernelGGL(k_strip4_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
-                               old, omid, oold, k1 - k0, om, md_scale, io);
+                               old, omid, oold, k1 - k0, om, md_scale, io, H);
         else
             hipLaunchKernelGGL(k_tile4_cheb, dim3(t, t, batch), dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
                                old, omid, oold, k1 - k0, om, md_scale, io);

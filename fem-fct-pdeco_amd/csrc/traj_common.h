@@ -103,25 +103,20 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
             fprintf(stderr, "[femfct] sweep kind %d: budget %d (krylov %d) worst %d kworst %d short %d/%d\n", kind, budget,
                     kbudget, worst, kworst, (int)short_budget, (int)kshort);
         if (!short_budget && !kshort) {
+            ctx->kind_good[kind] = budget;
             ctx->kind_budget[kind] = femfct_next_budget(ctx, worst, coarse);
             // Tiles report whole launches: `worst` = U launches of K sweeps, and every step was still above
             // the tolerance after (U-1)*K.  If one launch fewer of the deepest halo could cover that, try it
             // once (a failure is remembered per kind and costs one repeated sweep).
-            TilePlan tp, tp2;
-            if (femfct_tile_plan(ctx, &tp, false, budget, batch) && !femfct_tile4_wanted(ctx, batch) && worst > 0) {
-                const int U = (worst + tp.K - 1) / tp.K, lb = (U - 1) * tp.K;
-                for (int b_try = lb + 1; U >= 2 && b_try < worst; ++b_try) {
-                    if (!femfct_tile_plan(ctx, &tp2, false, b_try, batch)) break;
-                    if ((b_try + tp2.K - 1) / tp2.K > U - 1) continue;
-                    // largest budget that still fits U-1 launches
-                    int top = (U - 1) * tp2.K;
-                    while (femfct_tile_plan(ctx, &tp2, false, top + 1, batch) && (top + 1 + tp2.K - 1) / tp2.K <= U - 1 &&
-                           top + 1 < worst)
-                        ++top;
-                    const int known_fail = ctx->kind_fail.count(kind) ? ctx->kind_fail[kind] : 0;
-                    if (top > lb && top > known_fail && 10 * top >= 7 * worst) ctx->kind_budget[kind] = top;
-                    break;
-                }
+            int K = 0, U = 0, K2 = 0, U2 = 0;
+            if (femfct_jacobi_plan(ctx, budget, batch, &K, &U) && worst > 0) {
+                U = (worst + K - 1) / K;
+                const int lb = (U - 1) * K;
+                int top = 0;
+                for (int b_try = lb + 1; U >= 2 && b_try < worst; ++b_try)
+                    if (femfct_jacobi_plan(ctx, b_try, batch, &K2, &U2) && U2 <= U - 1) top = b_try;
+                const int known_fail = ctx->kind_fail.count(kind) ? ctx->kind_fail[kind] : 0;
+                if (top > lb && top > known_fail && 10 * top >= 7 * worst) ctx->kind_budget[kind] = top;
             }
             // (Chebyshev reports the count that meets tol/10 at its asymptotic rate: no extra margin)
             if (krylov)
@@ -135,7 +130,9 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
                 return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
                                    "low-order solve: residual %.3e after %d Jacobi sweeps (tol %.1e)", worst_res,
                                    budget, ctx->rel_tol);
-            ctx->kind_budget[kind] = femfct_grow_budget(ctx, budget);
+            // a failed attempt at fewer launches goes back to the budget that worked
+            const int good = ctx->kind_good.count(kind) ? ctx->kind_good[kind] : 0;
+            ctx->kind_budget[kind] = good > budget ? good : femfct_grow_budget(ctx, budget);
         }
         if (kshort && cheb) {
             // not contracting (complex spectrum outside the assumed interval) or out of budget: BiCGStab
