@@ -301,7 +301,7 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     dom_name = max(("jacobi", "cheb"), key=lambda k: kernels[k]["total_ms"])
     dom = kernels[dom_name]
     if dom["sweeps_per_launch"] > 1.5:
-        sym = {"jacobi": "k_strip4_jacobi<0>", "cheb": "k_strip4_cheb"}[dom_name] if n >= 150000 else \
+        sym = {"jacobi": "k_strip4_jacobi<0>", "cheb": "k_strip4_cheb"}[dom_name] if n >= 90000 else \
               {"jacobi": "k_tile_jacobi<H,0,0>", "cheb": "k_tile_cheb<H>"}[dom_name]
         label = f"{sym} (tile-fused, {dom['sweeps_per_launch']:.1f} sweeps per launch)"
     else:

@@ -1586,7 +1586,9 @@ bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch) {
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
     if (ctx->tile4_mode == 0) return false;
     if (ctx->tile4_mode == 2) return true;
-    return (int64_t)ctx->n * batch >= 150000;   // measured crossover at n = 6561: batch ~ 24
+    // measured crossover (register-resident strip kernels): n = 6561 between batch 12 and 16, single meshes
+    // between 257^2 and 321^2 nodes
+    return (int64_t)ctx->n * batch >= 90000;
 }
 
 int femfct_tile4_tiles(const femfct_ctx* ctx, int H) {
