@@ -297,11 +297,12 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
 }
 
 // ===========================================================================================
-// 2-D tile variants for the structured mesh in vertex order: a 1024-thread workgroup owns a
-// 16 x 16 tile and stages a 32 x 32 patch (halo 8 on every side) -- one node per thread, the
-// node's matrix row in registers, the iterate in LDS -- and runs up to 8 sweeps per launch.
-// Compared with row strips the patch is 1/2 .. 1/3 the rows per workgroup for the same K, there
-// is no column table to load, and 36 workgroups (81 x 81 mesh) share the work instead of 9.
+// 2-D tile variants for the structured mesh in vertex order: a 1024-thread workgroup stages a
+// 32 x 32 patch = (32 - 2H)^2 tile + halo H on every side -- one node per thread, the node's
+// matrix row in registers, the iterate in LDS -- and runs up to H sweeps per launch (the halo
+// shrinks by one ring per sweep).  H = 8 on large grids (least re-reading), 8..13 in the latency
+// regime (fewest launches: see femfct_tile_plan).  Compared with row strips there is no column
+// table to load and the work spreads over (N / (32 - 2H))^2 workgroups.
 // ===========================================================================================
 #define TILE_T 16
 #define TILE_H 8
@@ -1171,10 +1172,12 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, MatRef A, VecRef rhs, int64_t
 }
 
 // ===========================================================================================
-// Bandwidth-regime tiles: 64 x 64 patch, 48 x 48 tile + halo 8, four nodes per thread (1024
-// threads).  Each matrix row loaded from HBM is used for 8 sweeps and the halo re-read drops from
-// 4x (32-patch) to 1.78x: ~17 B of HBM traffic per row and sweep instead of ~35 (one-sweep
-// kernels: 104).  Used for large grids and for large batches of small trajectories.
+// Bandwidth-regime tiles: 64 x 64 patch, (64 - 2H)^2 tile + halo H (8..10), four nodes per thread
+// (1024 threads).  Each matrix row loaded from HBM is used for H sweeps and the halo re-read drops
+// from 4x (32-patch) to 1.78x: ~17 B of HBM traffic per row and sweep instead of ~35 (one-sweep
+// kernels: 104).  Used for large grids and for batches of small trajectories (femfct_tile4_wanted).
+// Two implementations: k_tile4_* keep the iterate as an LDS image (fixed halo 8; FEMFCT_T4_DPP=0),
+// k_strip4_* keep it in registers and exchange by DPP lane shifts (default, below).
 // ===========================================================================================
 #define T4_L 64
 #define T4_LD 65
