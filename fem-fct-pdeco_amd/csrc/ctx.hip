@@ -89,7 +89,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     ctx->kry_batch = 0;
     dev_free(&ctx->d_trMat); dev_free(&ctx->d_trBase); dev_free(&ctx->d_trBase2); dev_free(&ctx->d_trRhs2); dev_free(&ctx->d_trTmp);
     ctx->implicit_cols = false;
-    ctx->n = 0; ctx->W = 0; ctx->nnz_csr = 0; ctx->ws_batch = 0; ctx->have_mass = false; ctx->structured = false;
+    ctx->n = 0; ctx->W = 0; ctx->nnz_csr = 0; ctx->ws_batch = 0; ctx->have_mass = false; ctx->structured = false; ctx->mass_is_mesh = false;
 }
 
 void femfct_prof_begin(femfct_ctx* ctx, int cls) {
@@ -226,6 +226,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
+    if (const char* e = getenv("FEMFCT_GEOM_MASS")) ctx->geom_mass = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_DPP")) ctx->t4_dpp = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_K")) ctx->t4_k = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("FEMFCT_SPECIES_SOLVER")) ctx->species_solver = atoi(e);
@@ -503,6 +504,7 @@ int femfct_set_mass(femfct_ctx* ctx, const double* M_csr_vals_host, const double
     if (rc != FEMFCT_OK) return rc;
     HIP_TRY(ctx, hipMemcpy(ctx->d_ml, ml_host, sizeof(double) * ctx->n, hipMemcpyHostToDevice));
     ctx->have_mass = true;
+    ctx->mass_is_mesh = false;      // a user matrix: the geometry-defined mass kernels do not apply
     return FEMFCT_OK;
 }
 

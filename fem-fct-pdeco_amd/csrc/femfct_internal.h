@@ -46,6 +46,7 @@ struct femfct_ctx {
     int32_t* d_csr2ell = nullptr;  // [nnz_csr] linear ELL index of every CSR entry
     std::vector<int32_t> h_indptr, h_indices, h_csr2ell, h_cols;
     bool structured = false;
+    bool mass_is_mesh = false;     // d_M = the structured mesh's own mass matrix
     double a1 = 0, a2 = 0, h = 0;
     int32_t n_cells = 0, N = 0, order = 0;
     int32_t* d_d2v = nullptr;      // [n] dof -> vertex (structured, FEniCS order only)
@@ -68,6 +69,7 @@ struct femfct_ctx {
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always

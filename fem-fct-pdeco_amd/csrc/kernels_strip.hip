@@ -1575,6 +1575,75 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
         }
 }
 
+// Chebyshev iterations on the mesh's own consistent mass matrix without reading it: on the right-diagonal P1 mesh
+// m_ii = ntri |K| / 6 and m_ij = cnt_ij |K| / 12 (ntri triangles around the node, cnt_ij in {0,1,2} triangles on the
+// edge), so the row scaled by 1 / (md_scale m_ii) is cnt_ij / (2 md_scale ntri) -- small-integer ratios decided by
+// which of the four cells around the node exist.  HBM traffic per node and launch drops from 9 doubles (7 matrix
+// entries, rhs, iterate) to 2-3, and the interior update is one multiply of the neighbour sum.
+__global__ void __launch_bounds__(STRIP_T)
+k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const double* __restrict__ ymid_,
+                   const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
+                   CheOmegas om, double md_scale, int H) {
+    __shared__ double top[2][16][64], bot[2][16][64];
+    const int64_t voff = (int64_t)blockIdx.z * n;
+    const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
+    const int nc = N - 1;
+    const double inv_scale = 1.0 / md_scale;
+    Strip4Node g[4];
+    double bv[4], cw[4], ym[4], yo[4];
+    int pc[4];            // six 2-bit edge counts, slots E, NE, N, W, SW, S
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        g[r] = strip4_node(N, r, H);
+        bv[r] = 0.0; cw[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0; pc[r] = 0;
+        if (g[r].inside) {
+            const int gy = g[r].i / N, gx = g[r].i - gy * N;
+            const int c00 = (gx < nc && gy < nc), c10 = (gx > 0 && gy < nc), c01 = (gx < nc && gy > 0), c11 = (gx > 0 && gy > 0);
+            const int ntri = 2 * c00 + c10 + c01 + 2 * c11;
+            pc[r] = (c00 + c01) | ((2 * c00) << 2) | ((c00 + c10) << 4) | ((c10 + c11) << 6) | ((2 * c11) << 8) | ((c11 + c01) << 10);
+            cw[r] = 1.0 / (2.0 * md_scale * ntri);
+            bv[r] = b_[voff + g[r].i] * (12.0 / (md_scale * ntri * h * h));
+            if (ymid_) ym[r] = ymid_[voff + g[r].i];
+            if (yold_) yo[r] = yold_[voff + g[r].i];
+        }
+    }
+    for (int k = 0; k < K; ++k) {
+        const int par = k & 1;
+        bot[par][st][lx] = ym[0];
+        top[par][st][lx] = ym[3];
+        __syncthreads();
+        const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+        const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+        STRIP4_NEIGHBOURS(ym, above, below);
+        const double wk = om.w[k];
+        double yn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double sum;
+            if (pc[r] == 0xAAA) {          // interior node: all six edges carry two triangles
+                sum = 2.0 * (((STRIP4_NB(ym, above, below, r, 0) + STRIP4_NB(ym, above, below, r, 1)) +
+                              (STRIP4_NB(ym, above, below, r, 2) + STRIP4_NB(ym, above, below, r, 3))) +
+                             (STRIP4_NB(ym, above, below, r, 4) + STRIP4_NB(ym, above, below, r, 5)));
+            } else {
+                sum = 0.0;
+#pragma unroll
+                for (int s = 0; s < 6; ++s)
+                    sum = fma((double)((pc[r] >> (2 * s)) & 3), STRIP4_NB(ym, above, below, r, s), sum);
+            }
+            const double z = fma(-cw[r], sum, fma(-inv_scale, ym[r], bv[r]));
+            yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (g[r].owned) {
+            omid_[voff + g[r].i] = ym[r];
+            if (oold_) oold_[voff + g[r].i] = yo[r];
+        }
+}
+
 }  // namespace
 
 int femfct_tile4_init(femfct_ctx* ctx) {
@@ -1669,7 +1738,10 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
-        if (ctx->t4_dpp)
+        if (ctx->t4_dpp && ctx->geom_mass && ctx->structured && ctx->mass_is_mesh && !io_in)
+            hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
+                               mid, old, omid, oold, k1 - k0, om, md_scale, H);
+        else if (ctx->t4_dpp)
             hipLaunchKernelGGL(k_strip4_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
                                old, omid, oold, k1 - k0, om, md_scale, io, H);
         else

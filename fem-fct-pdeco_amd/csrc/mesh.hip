@@ -66,6 +66,7 @@ extern "C" int femfct_set_mesh_square(femfct_ctx* ctx, double a1, double a2, int
     int rc = femfct_install_pattern(ctx, n, STENCIL_W, cols, tslot);
     if (rc != FEMFCT_OK) return rc;
     ctx->structured = true;
+    ctx->mass_is_mesh = true;       // d_M is the P1 mass matrix of this mesh (femfct_set_mass would clear this)
     ctx->implicit_cols = (order == FEMFCT_ORDER_VERTEX);
     if (const char* e = getenv("FEMFCT_IMPLICIT")) ctx->implicit_cols = ctx->implicit_cols && atoi(e) != 0;
     ctx->a1 = a1; ctx->a2 = a2; ctx->n_cells = n_cells; ctx->N = (int32_t)N; ctx->order = order;
