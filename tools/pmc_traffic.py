@@ -18,7 +18,7 @@ import statistics
 import sys
 
 CLASS = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_tile_jacobi": "jacobi", "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb", "k_strip_jacobi": "jacobi",
-         "k_strip4_jacobi": "jacobi", "k_strip4_cheb": "cheb", "k_tile_build_jacobi": "jacobi", "k_tile_dudt_cheb": "dudt_rhs",
+         "k_strip4_jacobi": "jacobi", "k_strip4_cheb": "cheb", "k_strip4_cheb_mass": "cheb", "k_tile_build_jacobi": "jacobi", "k_tile_dudt_cheb": "dudt_rhs",
          "k_tile_cheb_flux_limit": "flux",
          "k_dudt_rhs": "dudt_rhs", "k_cheb": "cheb", "k_tile_cheb": "cheb", "k_strip_cheb": "cheb",
          "k_flux": "flux", "k_tile_flux_limit": "flux", "k_limit": "limit", "k_ops_solidbody": "assemble"}
