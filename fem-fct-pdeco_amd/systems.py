@@ -324,7 +324,35 @@ def assemble_mass(V: SquareMeshP1):
     order = np.lexsort((c, r))
     vals = ctx.ell_to_csr(ctx.mass_ell, int(mask.sum()))
     indptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))])
-    return csr_matrix((vals, c[order], indptr), shape=(n, n))
+    Mv = csr_matrix((vals, c[order], indptr), shape=(n, n))
+    return ell_matrix_to_dof_order(Mv, S.v2d)
+
+
+def ell_matrix_to_dof_order(Mv, v2d):
+    """device (vertex) ordering -> FEniCS DoF ordering of a sparse matrix: M_dof[v2d[i], v2d[j]] = M_v[i, j]"""
+    d2v = np.empty_like(v2d)
+    d2v[v2d] = np.arange(v2d.size)
+    out = Mv.tocsr()[d2v][:, d2v].tocsr()
+    out.sort_indices()
+    return out
+
+
+def device_matrix(V: SquareMeshP1, ell):
+    """A device ELL matrix of the mesh's context (e.g. ``_system(V).convection(wind)[0]``) as scipy CSR in
+    FEniCS DoF order -- what ``assemble_sparse`` would have returned."""
+    from scipy.sparse import csr_matrix
+    S = _system(V)
+    ctx = S.ctx
+    cols = ctx.ell_cols()
+    n, W = ctx.n, ctx.W
+    rows = np.tile(np.arange(n), W)
+    flat = cols.reshape(-1)
+    mask = (flat != rows) | (np.arange(W * n) < n)
+    r, c = rows[mask], flat[mask]
+    order = np.lexsort((c, r))
+    vals = ctx.ell_to_csr(ell, int(mask.sum()))
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))])
+    return ell_matrix_to_dof_order(csr_matrix((vals, c[order], indptr), shape=(n, n)), S.v2d)
 
 
 # ----------------------------------------------------------------------------- line search

@@ -1,0 +1,25 @@
+"""The example drivers (examples/) keep running: one short invocation each, as a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+EX = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+
+
+@pytest.mark.parametrize("script,args,needle", [
+    ("c1_forward_solidbody.py", ["--steps", "5"], "difference of the two end states"),
+    ("c2_solidbody_pdeco_finaltime.py", ["--iters", "1"], "PGD iterations in"),
+    ("c3_c4_systems_pdeco.py", ["nonlinear", "--iters", "1"], "PGD iterations in"),
+    ("c5_beta_sweep.py", ["--iters", "1"], "beta = "),
+])
+def test_example_runs(script, args, needle):
+    out = subprocess.run([sys.executable, os.path.join(EX, script)] + args, capture_output=True, text=True, timeout=300,
+                         cwd=EX)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert needle in out.stdout
+    if script.startswith("c1"):
+        diff = float(out.stdout.split("difference of the two end states:")[1].split()[0])
+        assert diff < 1e-11

@@ -235,3 +235,39 @@ def test_mimura_named_config_forward_synthetic(hp, monkeypatch):
     finally:
         S.close()
     assert rel(ug, uo) < 1e-9 and rel(vg, vo) < 1e-9
+
+
+def test_assemble_mass_and_armijo_line_search_ref_match_oracle(hp):
+    """assemble_mass (FEniCS DoF order) and the drop-in armijo_line_search_ref (helpers.py:1583-1713) against the
+    oracle's restatement on the nonlinear problem: same accepted trial, control, state and clobbering behaviour."""
+    from oracle import fct as ofct, traj as otraj
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    mesh, asm = _oracle(0.0, 1.0, 12)
+    V = hp.SquareMeshP1(0.0, 1.0, 12)
+    n, Nt, dt = V.nodes, 8, 2e-3
+    M = hp.assemble_mass(V)
+    Mo = asm.mass().tocsr()
+    assert abs(M - Mo).max() < 1e-16 and M.nnz == Mo.nnz
+    # convection matrix of the nonlinear wind through the same route
+    eps, _, wind = hp.get_nonlinear_eqns_params()
+    Aw = systems.device_matrix(V, systems._system(V).convection(wind, "nonlinear")[0])
+    assert abs(Aw - asm.convection(otraj.nonlinear_wind)).max() < 1e-15
+    tl = (Nt + 1) * n
+    rng = np.random.default_rng(5)
+    u0 = hp.nonlinear_equation_IC(0, 1, 1 / 12, n, V.vertex_to_dof)
+    z = lambda: np.concatenate([u0, np.zeros(Nt * n)])
+    c = 0.2 * np.ones(tl)
+    uo, _ = otraj.solve_nonlinear_equation(c, z(), None, asm, n, Nt, dt)
+    target = 0.8 * uo[Nt * n:] + 0.01
+    d = 0.5 * rng.standard_normal(tl)
+    J0 = ofct.cost_functional(uo, target, c, Nt, dt, Mo, 0.1, "finaltime")
+    solve_o = lambda ci, v1, v2: otraj.solve_nonlinear_equation(ci, v1, v2, asm, n, Nt, dt)
+    ro = ofct.armijo_line_search(uo.copy(), c, d, target, Nt, dt, -1.0, 1.0, 0.1, J0, n, "finaltime", Mo, max_iter=5,
+                                 nonlinear_solver=solve_o)
+    rg = hp.armijo_line_search_ref(uo.copy(), c, d, target, Nt, dt, -1.0, 1.0, 0.1, J0, n, "finaltime", V, max_iter=5,
+                                   nonlinear_solver=hp.solve_nonlinear_equation)
+    assert rg[2] == ro[2]                                   # k + 1
+    assert rel(rg[1], ro[1]) < 1e-14 and rel(rg[0], ro[0]) < 1e-9
+    with pytest.raises(ValueError):
+        hp.armijo_line_search_ref(uo, c, d, target, Nt, dt, -1.0, 1.0, 0.1, J0, n, "sometime", V,
+                                  nonlinear_solver=hp.solve_nonlinear_equation)
