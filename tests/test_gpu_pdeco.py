@@ -80,3 +80,29 @@ def test_pgd_argument_errors(hp):
         hp.projected_gradient_descent("nonlinear", V, (np.zeros(49),), (np.zeros(49),), 4, 1e-3, optim="sometime")
     with pytest.raises(ValueError):   # final-time problem needs final-time targets
         hp.projected_gradient_descent("nonlinear", V, (np.zeros(49),), (np.zeros(5 * 49),), 4, 1e-3)
+
+
+def test_descent_pointwise_is_bitwise_the_numpy_expression(hp):
+    """femfct_descent_pointwise evaluates the drivers' gradient expressions in NumPy's operation order."""
+    V = hp.SquareMeshP1(0.0, 1.0, 4)
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    S = systems.PDESystems(V, order=hp.ORDER_VERTEX)
+    ctx = S.ctx
+    try:
+        rng = np.random.default_rng(2)
+        cnt = 1000
+        c, p, q, u = (rng.standard_normal(cnt) for _ in range(4))
+        dc, dp, dq, du, out = ctx.array(c), ctx.array(p), ctx.array(q), ctx.array(u), ctx.zeros(cnt)
+        beta, gamma, r = 1e-3, 230.82, 0.1
+        ctx.descent_pointwise(cnt, beta, dc, dp, out)
+        assert np.array_equal(out.download(), -(beta * c - p))                       # nonlinear_FCT_PDECO_refactored.py:148
+        ctx.descent_pointwise(cnt, beta, dc, dp, out, scale=gamma / r)
+        assert np.array_equal(out.download(), -(beta * c - gamma / r * p))           # Schnak_FCT_PDECO_refactored.py:167
+        ctx.descent_pointwise(cnt, beta, dc, dq, out, y=du, divisor=r)
+        assert np.array_equal(out.download(), -(beta * c - q * u / r))               # chemotaxis_FCT_PDECO_AT_refactored.py:158
+        with pytest.raises(ValueError):
+            ctx.descent_pointwise(cnt, beta, dc, dq, out, y=du, divisor=0.0)
+        with pytest.raises(KeyError):
+            ctx.set_species_solver("gmres")
+    finally:
+        S.close()
