@@ -69,6 +69,7 @@ struct femfct_ctx {
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    int single_patch_min_batch = 8; // whole-mesh workgroups (N <= 48) for species solves from this batch size on (FEMFCT_SINGLE_PATCH_BATCH; 0 = off)
     bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
@@ -214,10 +215,11 @@ int femfct_tile4_init(femfct_ctx* ctx);
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
 int femfct_tile4_tiles(const femfct_ctx* ctx, int H = 8);
 int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps);
+bool femfct_single_patch(const femfct_ctx* ctx, int32_t batch);
 // launches and sweeps per launch the low-order solve of femfct_enqueue_step_mat will use for a budget
 bool femfct_jacobi_plan(const femfct_ctx* ctx, int budget, int batch, int* K, int* launches);
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch, int H = 8, int K = 8);
+                                int g_build, int32_t batch, int H = 8, int K = 8, int check_every = 0);
 int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
                               double* bufB0, double* bufB1, int32_t batch,

@@ -442,6 +442,7 @@ static bool species_plan(const femfct_ctx* ctx, TilePlan* tp, int32_t batch, int
 }
 
 int femfct_cheb_depth(const femfct_ctx* ctx, int32_t batch, int32_t budget) {
+    if (femfct_single_patch(ctx, batch)) return std::max(1, (int)budget);   // all iterations in one launch
     if (femfct_tile4_wanted(ctx, batch)) return 10;
     TilePlan tp;
     species_plan(ctx, &tp, batch, budget);
@@ -468,7 +469,7 @@ int femfct_enqueue_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t mat_sh
     io.om_dev = ctx->d_chs_om; io.om_bs = ctx->chs_om_cap; io.scale_dev = ctx->d_chs_scale;
     int rc;
     // y_out pointer is a placeholder: the last launch writes through io.out_ref
-    if (femfct_tile4_wanted(ctx, batch)) {
+    if (femfct_tile4_wanted(ctx, batch) || femfct_single_patch(ctx, batch)) {
         rc = femfct_enqueue_tile4_cheb(ctx, b, nullptr, nullptr, ctx->d_y0, 1, K, nullptr, 1.0, ctx->d_y0, ctx->d_y2, ctx->d_y1,
                                        ctx->d_rp, batch, &io);
     } else {

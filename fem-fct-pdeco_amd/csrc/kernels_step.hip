@@ -520,15 +520,18 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
         femfct_enqueue_kry_to_stepctl(ctx, (int)g.grid.x, batch);
         units = 0;
     } else if (tile4) {
+        const bool single = femfct_single_patch(ctx, batch);    // (reached only with FEMFCT_TILE4=2 on such meshes)
         const int h4 = femfct_tile4_halo(ctx, budget);
         const int t4 = femfct_tile4_tiles(ctx, h4);
         const bool big4 = (int64_t)t4 * t4 > FEMFCT_MAX_PARTIALS;
-        const int k4 = std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);   // sweeps per launch (t4_k < 8: measurement knob)
+        // sweeps per launch: the halo depth; a single patch runs the whole budget in one launch and stops by itself
+        const int k4 = single ? budget : std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);
         units = (budget + k4 - 1) / k4;
         part_count = big4 ? -1 : t4 * t4;
         ipu = k4;
         for (int s = 0; s < units; ++s)
-            femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch, h4, k4);
+            femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch, h4, k4,
+                                        single ? 2 : 0);
     } else if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
@@ -598,7 +601,9 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
 bool femfct_jacobi_plan(const femfct_ctx* ctx, int budget, int batch, int* K, int* launches) {
     TilePlan tp;
     if (!femfct_tile_plan(ctx, &tp, false, budget, batch)) return false;
-    if (femfct_tile4_wanted(ctx, batch)) {
+    if (femfct_tile4_wanted(ctx, batch) && femfct_single_patch(ctx, batch)) {
+        *K = budget;
+    } else if (femfct_tile4_wanted(ctx, batch)) {
         const int h4 = femfct_tile4_halo(ctx, budget);
         *K = std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);
     } else {

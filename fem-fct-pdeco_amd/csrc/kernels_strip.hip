@@ -21,7 +21,7 @@
 
 namespace {
 
-struct CheOmegas { double w[16]; };   // omegas of one launch (up to TILE_HMAX iterations)
+struct CheOmegas { double w[24]; };   // omegas of one launch (up to TILE_HMAX iterations; all 19 of ChebSI on a single patch)
 
 template <int RPT>
 __global__ void __launch_bounds__(STRIP_T)
@@ -1426,7 +1426,7 @@ template <int BIG>
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                 double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-                int g_build, double rel_tol, double* __restrict__ bigpart, int H) {
+                int g_build, double rel_tol, double* __restrict__ bigpart, int H, int check_every) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     __shared__ double smem[32];
@@ -1499,6 +1499,22 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
             // the nodes further out hold (they stay bounded: rows are diagonally dominant, outside rows are zero)
             if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
             xn[r] = acc;
+        }
+        // one workgroup = the whole mesh (check_every > 0): the residual of this sweep's input iterate is known
+        // to the workgroup, so it stops by itself -- exact sweep counts, the budget is only an upper bound
+        if (check_every > 0 && (k % check_every) == check_every - 1 && k < K - 1) {
+            double rk = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (g[r].owned) rk = fmax(rk, dg[r] * fabs(xn[r] - x[r]));
+            rk = block_reduce(rk, OpMax(), 0.0, smem);
+            if (rk <= rel_tol * bnorm) {                 // x (the input of this sweep) already meets the tolerance
+                if (threadIdx.x == 0) {
+                    ctl->done = 1; ctl->parity = (launch + 1) & 1; ctl->iters = launch * K + k;
+                    ctl->resid = bnorm > 0.0 ? rk / bnorm : 0.0;
+                }
+                break;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = xn[r];
@@ -1654,6 +1670,17 @@ int femfct_tile4_init(femfct_ctx* ctx) {
 }
 
 // bandwidth regime: the mesh (times the batch) is large enough that traffic, not launch latency, rules
+// One 64 x 64 patch covers the whole mesh (N <= 48 with halo 8): no halo limits the iterations per launch and one
+// workgroup advances one system without any grid-wide dependency.  Used for the long species solves of batched
+// small trajectories (Armijo trials / beta sweeps of the 41 x 41 configs: 221 Chebyshev iterations in one launch,
+// B workgroups in the time of one; measured at n = 1681: slower than 17 tile launches for B = 4, 7 % faster for
+// B = 10, 30 % for B = 20).  The FCT step itself stays on the fused 32-patch kernels unless FEMFCT_TILE4=2.
+bool femfct_single_patch(const femfct_ctx* ctx, int32_t batch) {
+    if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
+    if (!ctx->t4_dpp || ctx->t4_k != 8 || ctx->tile4_mode == 0) return false;
+    return ctx->N <= T4_L - 2 * T4_H && batch >= ctx->single_patch_min_batch;
+}
+
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch) {
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
     if (ctx->tile4_mode == 0) return false;
@@ -1673,6 +1700,7 @@ int femfct_tile4_tiles(const femfct_ctx* ctx, int H) {
 // redundancy (48 / (64 - 2H))^2.  E.g. 36 sweeps = 4 x 9, 19 Chebyshev iterations = 10 + 9.
 int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
     if (!ctx->t4_dpp || ctx->t4_k != 8) return T4_H;   // LDS-image variant / measurement knob: fixed geometry
+    if (ctx->N <= T4_L - 2 * T4_H) return T4_H;        // one patch covers the mesh: nothing to trade
     int best_h = T4_H;
     double best = 1e300;
     for (int h = T4_H; h <= 10; ++h) {
@@ -1685,7 +1713,7 @@ int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
 }
 
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch, int H, int K) {
+                                int g_build, int32_t batch, int H, int K, int check_every) {
     const int t = femfct_tile4_tiles(ctx, H);
     const bool big = (int64_t)t * t > FEMFCT_MAX_PARTIALS;
     dim3 grid(t, t, batch);
@@ -1694,12 +1722,12 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     if (ctx->t4_dpp) {
         if (big) {
             hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every);
             hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                                ctx->d_ctl, launch);
         } else {
             hipLaunchKernelGGL(k_strip4_jacobi<0>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every);
         }
     } else if (big) {
         hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
@@ -1720,16 +1748,18 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
     ChebIO io0{};
     if (io_in) io0 = *io_in;
     io0.mid_ref = make_ref(nullptr); io0.mid_bs = 0; io0.out_ref = make_ref(nullptr); io0.out_bs = 0;
-    const int H = femfct_tile4_halo(ctx, k_last - k_first + 1);
+    const bool single = femfct_single_patch(ctx, batch);
+    const int H = single ? T4_H : femfct_tile4_halo(ctx, k_last - k_first + 1);
+    const int per_launch = single ? ((io_in && io_in->om_dev) ? k_last - k_first + 1 : 24) : H;   // by-value omega table: 24
     const int t = femfct_tile4_tiles(ctx, H);
     const size_t lds = (size_t)3 * T4_BUF * 8;
     const double* mid = in_mid;
     const double* old = in_old;
     int which = 0;
-    for (int k0 = k_first; k0 <= k_last; k0 += H) {
-        int k1 = std::min(k_last + 1, k0 + H);
+    for (int k0 = k_first; k0 <= k_last; k0 += per_launch) {
+        int k1 = std::min(k_last + 1, k0 + per_launch);
         CheOmegas om;
-        for (int k = k0; k < k1; ++k) om.w[k - k0] = omegas ? omegas[k - 1] : 0.0;
+        for (int k = k0; k < k1 && k - k0 < 24; ++k) om.w[k - k0] = omegas ? omegas[k - 1] : 0.0;
         const bool last = (k1 == k_last + 1);
         double* omid = last ? y_out : (which ? bufB0 : bufA0);
         double* oold = last ? nullptr : (which ? bufB1 : bufA1);

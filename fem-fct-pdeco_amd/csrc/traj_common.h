@@ -105,11 +105,14 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         if (!short_budget && !kshort) {
             ctx->kind_good[kind] = budget;
             ctx->kind_budget[kind] = femfct_next_budget(ctx, worst, coarse);
+            // whole-mesh workgroups stop by themselves: the budget is only an upper bound, keep a margin
+            const bool single = femfct_tile4_wanted(ctx, batch) && femfct_single_patch(ctx, batch);
+            if (single) ctx->kind_budget[kind] = std::min(ctx->max_iters, worst + 6);
             // Tiles report whole launches: `worst` = U launches of K sweeps, and every step was still above
             // the tolerance after (U-1)*K.  If one launch fewer of the deepest halo could cover that, try it
             // once (a failure is remembered per kind and costs one repeated sweep).
             int K = 0, U = 0, K2 = 0, U2 = 0;
-            if (femfct_jacobi_plan(ctx, budget, batch, &K, &U) && worst > 0) {
+            if (!single && femfct_jacobi_plan(ctx, budget, batch, &K, &U) && worst > 0) {
                 U = (worst + K - 1) / K;
                 const int lb = (U - 1) * K;
                 int top = 0;
