@@ -156,10 +156,18 @@ class SystemPDECO:
             if np.asarray(t).size != tsz:
                 raise ValueError(f"target of {np.asarray(t).size} values, expected {tsz} for optim='{P['optim']}'")
 
+        def replicate(one, count, reps):
+            """reps copies of a device vector, made on the device"""
+            d = self._zeros(reps * count)
+            for b in range(reps):
+                d.copy_from(one, count, dst_off=b * count)
+            return d
+
         def traj0(x0, reps=1):
-            a = np.zeros((reps, tl))
-            a[:, :n] = np.asarray(x0, dtype=np.float64)
-            return self._up(a)
+            a = np.zeros(tl)
+            a[:n] = np.asarray(x0, dtype=np.float64)
+            one = self._up(a)
+            return one if reps == 1 else replicate(one, tl, reps)
 
         u = traj0(ic[0])
         v = traj0(ic[1]) if self.two else None
@@ -173,7 +181,7 @@ class SystemPDECO:
         cB = self._zeros(B * tl)
         if speculative:
             ckB = self._zeros(B * tl)
-            tgB = [self._up(np.tile(np.asarray(t, dtype=np.float64).ravel(), B)) for t in targets]
+            tgB = [replicate(t, tsz, B) for t in tg]
         else:
             ckB, tgB = c, tg
 

@@ -208,11 +208,12 @@ def pgd_solidbody(prob: SolidBodyDrift, u0, uhat, c0, beta, c_lower, c_upper, it
     if uhat.size != (tl if alltime else n):
         raise ValueError(f"target of {uhat.size} values, expected {tl if alltime else n} for optim='{optim}'")
     uh = ctx.array(uhat)
-    uhB = ctx.array(np.tile(uhat, B))
+    uhB = ctx.zeros(B * uhat.size)                      # B copies of the target, replicated on the device
+    for k in range(B):
+        uhB.copy_from(uh, uhat.size, dst_off=k * uhat.size)
     cB, uB, ckB = ctx.zeros(B * tl), ctx.zeros(B * tl), ctx.zeros(B * tl)
-    init = np.zeros((B, tl))
-    init[:, :n] = u0
-    uB.upload(init.reshape(-1))
+    for k in range(B):                                  # level 0 of every trial trajectory = the initial condition
+        uB.copy_from(u, n, dst_off=k * tl)
     hist = dict(cost=[], armijo_k=[], step=[], rel_change=[])
     if alltime:
         u.copy_from(uh, tl - n, dst_off=n, src_off=n)      # uk = np.copy(uhat_all), level 0 = u0
