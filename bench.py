@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="independent trajectories per launch on each GPU")
     ap.add_argument("--roofline-cells", type=int, default=2048, help="cells per side of the roofline mesh (0: skip)")
     ap.add_argument("--roofline-steps", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=20, help="forward+adjoint oracle steps each (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=250,
+                    help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~8 s of one core (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
     ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
     args = ap.parse_args()
@@ -344,7 +345,7 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample):
     nb = mesh.dof_neighbors()
     A = -(sb.A_u(c[n:2 * n]))
     t1 = time.perf_counter()
-    reps = 2
+    reps = 4
     for _ in range(reps):
         ofct.fct_step_lil(A, np.zeros(n), u0, dt, n, sb.cm.M, sb.cm.ML, nb)
     t_lil = (time.perf_counter() - t1) / reps
