@@ -271,3 +271,23 @@ def test_assemble_mass_and_armijo_line_search_ref_match_oracle(hp):
     with pytest.raises(ValueError):
         hp.armijo_line_search_ref(uo, c, d, target, Nt, dt, -1.0, 1.0, 0.1, J0, n, "sometime", V,
                                   nonlinear_solver=hp.solve_nonlinear_equation)
+
+
+def test_chemotaxis_adjoint_only_harness(hp):
+    """The reference's solve-the-adjoint-only harness (chemotaxis_adjoint_equations.py:94-107): constant states
+    uhat = 1, vhat = 2, u = 0.8 uhat, v = 0.8 vhat, control 100, all-time misfit -- device sweep against the oracle,
+    plus what the constant data implies: spatially constant adjoints (every node sees the same equations)."""
+    from oracle import traj as otraj
+    mesh, asm = _oracle(0.0, 1.0, 16)
+    V = hp.SquareMeshP1(0.0, 1.0, 16)
+    n, Nt, dt = V.nodes, 10, 1e-3
+    tl = (Nt + 1) * n
+    uhat, vhat = np.ones(tl), 2 * np.ones(tl)
+    uk, vk, control = 0.8 * uhat, 0.8 * vhat, 100 * np.ones(tl)
+    po, qo = otraj.solve_adjoint_chtxs_system(uk, vk, uhat, vhat, np.zeros(tl), np.zeros(tl), control, Nt * dt, asm, n, Nt,
+                                              dt, None, "alltime")
+    pg, qg = hp.solve_adjoint_chtxs_system(uk, vk, uhat, vhat, np.zeros(tl), np.zeros(tl), control, Nt * dt, V, n, Nt, dt,
+                                           None, "alltime")
+    assert rel(pg, po) < 1e-9 and rel(qg, qo) < 1e-9
+    assert not pg[Nt * n:].any() and not qg[Nt * n:].any()          # p(T) = q(T) = 0
+    assert np.abs(pg).max() > 0 and np.abs(qg).max() > 0
