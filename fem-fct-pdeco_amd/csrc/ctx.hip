@@ -227,6 +227,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
     if (const char* e = getenv("FEMFCT_SINGLE_PATCH_BATCH")) { int v = atoi(e); ctx->single_patch_min_batch = v > 0 ? v : (1 << 30); }
+    if (const char* e = getenv("FEMFCT_MESH_SOLVE")) ctx->mesh_solve = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_GEOM_MASS")) ctx->geom_mass = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_DPP")) ctx->t4_dpp = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_K")) ctx->t4_k = std::min(8, std::max(1, atoi(e)));

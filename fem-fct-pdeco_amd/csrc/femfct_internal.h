@@ -69,6 +69,8 @@ struct femfct_ctx {
     int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
+    bool mesh_solve = true;         // species solves of meshes with n <= 4096 as one workgroup per system (FEMFCT_MESH_SOLVE)
+    bool mesh_solve_attr[8] = {false, false, false, false, false, false, false, false};
     int single_patch_min_batch = 8; // whole-mesh workgroups (N <= 48) for species solves from this batch size on (FEMFCT_SINGLE_PATCH_BATCH; 0 = off)
     bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)

@@ -57,6 +57,7 @@ int femfct_enqueue_bicgstab(femfct_ctx* ctx, const double* mat, int32_t mat_shar
                             bool lowsolve = false);
 // Chebyshev variant (structured vertex-order mesh) and the per-sweep-kind choice between the two
 bool femfct_species_cheb(const femfct_ctx* ctx, int kind);
+bool femfct_mesh_solve_fits(const femfct_ctx* ctx);
 int femfct_enqueue_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
                               int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget, double tau);
 int femfct_enqueue_species_solve(femfct_ctx* ctx, int kind, const double* mat, int32_t mat_shared, const double* b,

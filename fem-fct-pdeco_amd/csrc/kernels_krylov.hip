@@ -430,6 +430,7 @@ static double element_lambda_min(double h, double tau) {
 
 bool femfct_species_cheb(const femfct_ctx* ctx, int kind) {
     if (ctx->species_solver != 0 || ctx->kind_cheb_off.count(kind)) return false;
+    if (ctx->structured && femfct_mesh_solve_fits(ctx)) return true;     // one workgroup per system (any ordering)
     if (!ctx->use_strips || !ctx->use_tiles || !ctx->implicit_cols || ctx->W != 7) return false;
     TilePlan tp;
     return femfct_tile_plan(ctx, &tp, false);
@@ -439,6 +440,163 @@ bool femfct_species_cheb(const femfct_ctx* ctx, int kind) {
 // every workgroup gets its own CU: 214 iterations = 17 launches of 13 instead of 22 of 10)
 static bool species_plan(const femfct_ctx* ctx, TilePlan* tp, int32_t batch, int32_t budget) {
     return femfct_tile_plan(ctx, tp, false, budget > 0 ? budget : 0, batch);
+}
+
+// -------------------------------------------------------------------------------------------
+// The whole species solve in ONE launch for meshes that fit a workgroup (n <= 1024 * NPT): one workgroup per
+// batch member keeps the iterate in LDS (three rotating buffers indexed by node), the rows pre-scaled in
+// registers, and runs the spectrum bound (k_chs_setup), every Chebyshev iteration, the convergence test and the
+// bookkeeping (k_chs_check / k_chs_finish) itself -- __syncthreads() is the only synchronisation.  The omegas come
+// from the three-term recurrence; z = rmd * r is the scaled residual of the current iterate, so the workgroup
+// tests ||r||_inf <= tol ||b||_inf every CHECK iterations and stops by itself (iters = the exact count).
+// Any ELL pattern / ordering (neighbours through the column table).  Configs C3/C4 (n = 1681): 221 iterations of
+// the Schnakenberg solve take one launch instead of 17 tile launches + 3 bookkeeping launches.
+// -------------------------------------------------------------------------------------------
+namespace {
+
+template <int NPT>
+__global__ void __launch_bounds__(1024)
+k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ A_, int ashared,
+                  const double* __restrict__ b_, VecRef x0_ref, int64_t x0_bs, VecRef out_ref, int64_t out_bs,
+                  const double* __restrict__ Mdiag, const double* __restrict__ Kdiag, double tau, double lam_e, double lmax,
+                  int K, double rel_tol, KrylovCtl* __restrict__ ctl_) {
+    constexpr int CHECK = 16, W = 7;      // structured P1 mesh: seven slots (checked by the launcher)
+    extern __shared__ double ybuf[];          // 3 * n doubles
+    __shared__ double smem[32];
+    const int bz = blockIdx.x;
+    const double* A = A_ + (ashared ? 0 : (int64_t)bz * Wrt * n);
+    const double* b = b_ + (int64_t)bz * n;
+    const double* x0 = vec_ptr(x0_ref) + bz * x0_bs;
+    double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bs;
+    double *y_old = ybuf, *y_mid = ybuf + n, *y_new = ybuf + 2 * n;
+    // spectrum bound of D^-1 A (see k_chs_setup)
+    double mn = INFINITY, bmax = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        mn = fmin(mn, (tau >= 0.0 ? Mdiag[i] + tau * Kdiag[i] : Mdiag[i]) / A[i]);
+        bmax = fmax(bmax, fabs(b[i]));
+    }
+    mn = block_reduce(mn, OpMin(), INFINITY, smem);
+    bmax = block_reduce(bmax, OpMax(), 0.0, smem);
+    double lmin = 0.9 * lam_e * fmin(mn, 1.0);
+    if (!(lmin > 0.0) || !(lmin < lmax)) lmin = 0.5 * lmax;
+    const double rho = (lmax - lmin) / (lmax + lmin);
+    const double scale = 0.5 * (lmin + lmax), inv_scale = 1.0 / scale;
+    const double xi = 1.0 / rho, theta = log(xi + sqrt(xi * xi - 1.0));
+    // rows of the thread's nodes, scaled by 1 / (scale * a_ii)
+    int idx[NPT], nb[NPT][W - 1];
+    double ms[NPT][W - 1], bs[NPT], sa[NPT], ym[NPT], yo[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+        const int i = threadIdx.x + q * 1024;
+        idx[q] = i < n ? i : -1;
+        bs[q] = 0.0; sa[q] = 1.0; ym[q] = 0.0; yo[q] = 0.0;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) { ms[q][s] = 0.0; nb[q][s] = 0; }
+        if (i < n) {
+            sa[q] = scale * A[i];
+            const double rmd = 1.0 / sa[q];
+#pragma unroll
+            for (int s = 1; s < W; ++s) {
+                const int64_t e = (int64_t)s * n + i;
+                ms[q][s - 1] = A[e] * rmd;
+                nb[q][s - 1] = cols[e];
+            }
+            bs[q] = b[i] * rmd;
+            ym[q] = x0[i];
+            y_mid[i] = ym[q];
+        }
+    }
+    __syncthreads();
+    double omega = 1.0, res = INFINITY;
+    int k = 0;
+    for (; k < K; ++k) {
+        double zmax = 0.0;
+        double yn[NPT];
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            double z = fma(-inv_scale, ym[q], bs[q]);
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) z = fma(-ms[q][s], y_mid[nb[q][s]], z);
+            zmax = fmax(zmax, fabs(z) * sa[q]);                 // |r_i| of the current iterate
+            yn[q] = omega * (z + ym[q] - yo[q]) + yo[q];
+        }
+        if ((k % CHECK) == 0) {                                  // uniform decision: everybody reduces the same value
+            res = block_reduce(zmax, OpMax(), 0.0, smem);
+            if (res <= rel_tol * bmax) break;                    // y_mid already meets the tolerance
+        }
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            if (idx[q] >= 0) y_new[idx[q]] = yn[q];
+            yo[q] = ym[q];
+            ym[q] = yn[q];
+        }
+        __syncthreads();
+        double* t = y_old; y_old = y_mid; y_mid = y_new; y_new = t;
+        omega = (k == 0) ? 1.0 / (1.0 - 0.5 * rho * rho) : 1.0 / (1.0 - 0.25 * rho * rho * omega);
+    }
+    if (k == K) {                                                // budget exhausted: residual of the last iterate
+        double zmax = 0.0;
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            double z = fma(-inv_scale, ym[q], bs[q]);
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) z = fma(-ms[q][s], y_mid[nb[q][s]], z);
+            zmax = fmax(zmax, fabs(z) * sa[q]);
+        }
+        res = block_reduce(zmax, OpMax(), 0.0, smem);
+    }
+#pragma unroll
+    for (int q = 0; q < NPT; ++q)
+        if (idx[q] >= 0) out[idx[q]] = ym[q];
+    if (threadIdx.x == 0) {
+        KrylovCtl* c = ctl_ + bz;
+        const double rr = bmax > 0.0 ? res / bmax : (res > 0.0 ? INFINITY : 0.0);
+        c->flags = FEMFCT_FLAG_CHEBYSHEV;
+        c->done = 1;
+        c->resid = rr;
+        c->bnorm = bmax;
+        c->alpha = theta;
+        c->omega = lmin;
+        if (rr <= rel_tol) {
+            c->iters = k + CHECK;      // the test runs every CHECK iterations: an upper bound of what was needed
+        } else {
+            double need = K;
+            if (rr < INFINITY) need = K + log(rr / (0.1 * rel_tol)) / theta;
+            c->iters = (int)ceil(fmin(fmax(need, 1.0), 1.0e6));
+            c->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
+        }
+    }
+}
+
+}  // namespace
+
+// meshes whose species solve runs as one workgroup per system
+// (two nodes per thread; the four-node variant for n <= 4096 spills at 128 VGPRs and is not used)
+bool femfct_mesh_solve_fits(const femfct_ctx* ctx) { return ctx->mesh_solve && ctx->n <= 2048 && ctx->W == 7; }
+
+static int enqueue_mesh_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
+                                   int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget, double tau) {
+    const int n = ctx->n, W = ctx->W;
+    const double lam_e = tau >= 0.0 ? element_lambda_min(ctx->h, tau) : 0.5;
+    const size_t lds = (size_t)3 * n * sizeof(double);
+    KrylovCtl* ctl = (KrylovCtl*)ctx->d_kry_ctl;
+    femfct_prof_begin(ctx, KC_OTHER);
+#define MS(NPT)                                                                                                          \
+    do {                                                                                                                 \
+        if (!ctx->mesh_solve_attr[NPT])                                                                                  \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_mesh_cheb_solve<NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                             3 * 1024 * NPT * 8));                                                       \
+        ctx->mesh_solve_attr[NPT] = true;                                                                                \
+        hipLaunchKernelGGL((k_mesh_cheb_solve<NPT>), dim3(batch), dim3(1024), lds, ctx->stream, n, W, ctx->d_cols, mat,  \
+                           mat_shared, b, x0, x0_bs, x_out, out_bs, (const double*)ctx->d_M, (const double*)ctx->d_Ad, tau, \
+                           lam_e, 2.2, (int)budget, ctx->kry_tol, ctl);                                                  \
+    } while (0)
+    MS(2);
+#undef MS
+    femfct_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "Chebyshev solve launch failed: %s", hipGetErrorString(e));
+    return FEMFCT_OK;
 }
 
 int femfct_cheb_depth(const femfct_ctx* ctx, int32_t batch, int32_t budget) {
@@ -451,6 +609,8 @@ int femfct_cheb_depth(const femfct_ctx* ctx, int32_t batch, int32_t budget) {
 
 int femfct_enqueue_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t mat_shared, const double* b, VecRef x0,
                               int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget, double tau) {
+    if (femfct_mesh_solve_fits(ctx))
+        return enqueue_mesh_cheb_solve(ctx, mat, mat_shared, b, x0, x0_bs, x_out, out_bs, batch, budget, tau);
     const int n = ctx->n, W = ctx->W;
     const int depth = femfct_cheb_depth(ctx, batch, budget);
     int K = ((budget + depth - 1) / depth) * depth;
