@@ -291,3 +291,34 @@ def test_chemotaxis_adjoint_only_harness(hp):
     assert rel(pg, po) < 1e-9 and rel(qg, qo) < 1e-9
     assert not pg[Nt * n:].any() and not qg[Nt * n:].any()          # p(T) = q(T) = 0
     assert np.abs(pg).max() > 0 and np.abs(qg).max() > 0
+
+
+def test_species_solver_falls_back_to_bicgstab_when_chebyshev_runs_out_of_iterations(hp):
+    """With an iteration cap between what BiCGStab (~70) and the Chebyshev iteration (~150) need for the
+    Schnakenberg species solve, the sweep must notice the failed Chebyshev solves, switch that kind of sweep to
+    BiCGStab, repeat it and still deliver the reference result; with a cap below both it must raise."""
+    from oracle import traj as otraj
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    mesh, asm = _oracle(0.0, 1.0, 40)
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 4, 5e-4
+    u0, v0 = hp.schnak_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+    z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
+    uo, vo = otraj.solve_schnak_system(np.full((Nt + 1) * n, 0.1), z(u0), z(v0), asm, n, Nt, dt)
+    S = systems.PDESystems(V, order=hp.ORDER_FENICS)
+    ctx = S.ctx
+    try:
+        par, wind = systems._schnak_par()
+        Aw, _ = S.convection(wind, "schnak")
+        c = ctx.array(np.full(n, 0.1))
+        ctx.set_krylov(1e-13, 100)
+        u, v = ctx.array(z(u0)), ctx.array(z(v0))
+        ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0)
+        k = ctx.traj_krylov_info(Nt)
+        assert np.all((k["flags"] & hp.FLAG_CHEBYSHEV) == 0) and np.all((k["flags"] & hp.FLAG_SOLVER_BUDGET) == 0)
+        assert rel(u.download(), uo) < 1e-9 and rel(v.download(), vo) < 1e-9
+        ctx.set_krylov(1e-13, 20)
+        with pytest.raises(hp.NotConverged):
+            ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0)
+    finally:
+        S.close()
