@@ -461,14 +461,15 @@ k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double
                   const double* __restrict__ Mdiag, const double* __restrict__ Kdiag, double tau, double lam_e, double lmax,
                   int K, double rel_tol, KrylovCtl* __restrict__ ctl_) {
     constexpr int CHECK = 16, W = 7;      // structured P1 mesh: seven slots (checked by the launcher)
-    extern __shared__ double ybuf[];          // 3 * n doubles
+    extern __shared__ double ybuf[];          // 2 * n doubles: the iterate the neighbours read, and the next one
     __shared__ double smem[32];
     const int bz = blockIdx.x;
     const double* A = A_ + (ashared ? 0 : (int64_t)bz * Wrt * n);
     const double* b = b_ + (int64_t)bz * n;
     const double* x0 = vec_ptr(x0_ref) + bz * x0_bs;
     double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bs;
-    double *y_old = ybuf, *y_mid = ybuf + n, *y_new = ybuf + 2 * n;
+    double* const B0 = ybuf;
+    double* const B1 = ybuf + n;
     // spectrum bound of D^-1 A (see k_chs_setup)
     double mn = INFINITY, bmax = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -503,13 +504,18 @@ k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double
             }
             bs[q] = b[i] * rmd;
             ym[q] = x0[i];
-            y_mid[i] = ym[q];
+            B0[i] = ym[q];
         }
     }
     __syncthreads();
     double omega = 1.0, res = INFINITY;
     int k = 0;
+#pragma unroll 2
     for (; k < K; ++k) {
+        // y_{k-1} lives in registers only; the two LDS buffers alternate by the parity of k (unrolled by two, so
+        // every LDS access has a constant base)
+        const double* y_mid = (k & 1) ? B1 : B0;
+        double* y_new = (k & 1) ? B0 : B1;
         double zmax = 0.0;
         double yn[NPT];
 #pragma unroll
@@ -522,7 +528,7 @@ k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double
         }
         if ((k % CHECK) == 0) {                                  // uniform decision: everybody reduces the same value
             res = block_reduce(zmax, OpMax(), 0.0, smem);
-            if (res <= rel_tol * bmax) break;                    // y_mid already meets the tolerance
+            if (res <= rel_tol * bmax) break;                    // the current iterate already meets the tolerance
         }
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
@@ -531,10 +537,10 @@ k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double
             ym[q] = yn[q];
         }
         __syncthreads();
-        double* t = y_old; y_old = y_mid; y_mid = y_new; y_new = t;
         omega = (k == 0) ? 1.0 / (1.0 - 0.5 * rho * rho) : 1.0 / (1.0 - 0.25 * rho * rho * omega);
     }
     if (k == K) {                                                // budget exhausted: residual of the last iterate
+        const double* y_mid = (k & 1) ? B1 : B0;
         double zmax = 0.0;
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
@@ -578,14 +584,14 @@ static int enqueue_mesh_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t m
                                    int64_t x0_bs, VecRef x_out, int64_t out_bs, int32_t batch, int32_t budget, double tau) {
     const int n = ctx->n, W = ctx->W;
     const double lam_e = tau >= 0.0 ? element_lambda_min(ctx->h, tau) : 0.5;
-    const size_t lds = (size_t)3 * n * sizeof(double);
+    const size_t lds = (size_t)2 * n * sizeof(double);
     KrylovCtl* ctl = (KrylovCtl*)ctx->d_kry_ctl;
     femfct_prof_begin(ctx, KC_OTHER);
 #define MS(NPT)                                                                                                          \
     do {                                                                                                                 \
         if (!ctx->mesh_solve_attr[NPT])                                                                                  \
             HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_mesh_cheb_solve<NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                             3 * 1024 * NPT * 8));                                                       \
+                                             2 * 1024 * NPT * 8));                                                       \
         ctx->mesh_solve_attr[NPT] = true;                                                                                \
         hipLaunchKernelGGL((k_mesh_cheb_solve<NPT>), dim3(batch), dim3(1024), lds, ctx->stream, n, W, ctx->d_cols, mat,  \
                            mat_shared, b, x0, x0_bs, x_out, out_bs, (const double*)ctx->d_M, (const double*)ctx->d_Ad, tau, \
