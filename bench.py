@@ -195,7 +195,7 @@ def main():
     # ------------------------------------------------------------ roofline mesh
     if rank == 0 and args.roofline_cells > 0:
         result["roofline"] = roofline(hp, solvers, args.roofline_cells, args.roofline_steps, local_rank)
-    if rank == 0 and args.batched:
+    if rank == 0 and world == 1 and args.batched:
         # the same sweep with B independent trajectories per launch (beta values / Armijo trials on one GPU)
         result["batched"] = []
         for Bx in [int(t) for t in args.batched.split(",") if t]:
@@ -222,7 +222,7 @@ def main():
                                       "ms_per_step": 1e3 * el})
             for a in (cb, ub, pb, uhb):
                 a.free()
-    if rank == 0 and args.pgd_iters > 0:
+    if rank == 0 and world == 1 and args.pgd_iters > 0:
         # the full optimisation loop of configs[1] (finaltime_Garvie.py:164-330), everything in HBM;
         # speculative = all 10 Armijo trial steps as one batch of independent trajectories
         pg = {}
@@ -235,7 +235,7 @@ def main():
                 "s_per_pgd_iteration": dt_it, "armijo_trials": hist["armijo_k"], "cost": hist["cost"][-1]}
         pg["cost_rel_diff"] = abs(pg["speculative"]["cost"] - pg["sequential"]["cost"]) / abs(pg["sequential"]["cost"])
         result["pgd_c2"] = pg
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:      # the CPU baseline is an N = 1 figure
         result["cpu_baseline"] = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample)
     if dist is not None:
         dist.barrier()
