@@ -245,10 +245,11 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
     prob.close()
 
 
-@pytest.mark.parametrize("nc,order", [(40, 0), (40, 1), (767, 0), (2303, 0)])
+@pytest.mark.parametrize("nc,order", [(40, 0), (40, 1), (330, 0), (767, 0), (1000, 0), (2303, 0)])
 def test_fused_kernels_agree_with_one_sweep_kernels(hp, solvers, nc, order):
-    """Strip / tile multi-sweep kernels (768^2 nodes: 64-patch tiles; 2304^2 nodes: 64-patch tiles with
-    the separate residual-reduce kernel) against the plain one-sweep kernels on the same inputs."""
+    """Strip / tile multi-sweep kernels (331^2, 768^2, 1001^2 nodes: 64-patch strip kernels with partial edge
+    tiles and halo depths 8-10; 2304^2 nodes: the separate residual-reduce kernel) against the plain one-sweep
+    kernels on the same inputs."""
     Nt = 3 if nc < 2000 else 1
     mesh = hp.SquareMeshP1(-1, 1, nc)
     n = mesh.nodes
@@ -273,7 +274,7 @@ def test_fused_kernels_agree_with_one_sweep_kernels(hp, solvers, nc, order):
 
 
 def test_large_batch_uses_bandwidth_tiles_and_matches_single(hp, solvers):
-    """n * batch >= 150k switches to the 64 x 64-patch kernels (four nodes per thread)."""
+    """n * batch >= 90k switches to the 64 x 64-patch kernels (four nodes per thread)."""
     rng = np.random.default_rng(9)
     nc, Nt, dt, B = 80, 2, 1e-3, 64
     mesh = hp.SquareMeshP1(-1, 1, nc)
