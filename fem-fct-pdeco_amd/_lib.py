@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_NOMEM = 0, 1, 2, 3, 4
 FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV = 1, 2, 4, 8
 ORDER_VERTEX, ORDER_FENICS = 0, 1
 SOLVER_JACOBI, SOLVER_BICGSTAB = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FemFctError(RuntimeError):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FEMFCT_ABI_VERSION 1
+#define FEMFCT_ABI_VERSION 2   /* 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
 
 typedef struct femfct_ctx femfct_ctx;
 
