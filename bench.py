@@ -1,34 +1,48 @@
 #!/usr/bin/env python3
 """Benchmark of the FEM-FCT forward+adjoint hot path on MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N > 1 launched by
-``python -m torch.distributed.run --nproc-per-node N ...``, one rank per GPU) prints ONE
-JSON line on rank 0.
+Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line (rank 0).
+For N > 1 it either runs under a launcher (``python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...``: RANK/LOCAL_RANK/WORLD_SIZE in the environment) or, when WORLD_SIZE is
+unset, starts that launcher itself as a child process BEFORE anything touches the GPU, relays the
+child's JSON line and exits with its status (the process image is never replaced).
 
-Workload (BASELINE.json configs[1], "C2" of SURVEY.md 8d): solid-body rotation + drift
-control on [-1,1]^2, 81x81 P1 nodes (dx = 0.025, n = 6561), dt = 1e-3, T = 0.25 (250 steps),
-eps = 0, rotation (-y,x)*40/pi, drift b = (1,1), slotted-disc initial condition.
-One bench "step" = one cost + gradient evaluation of the projected-gradient loop:
-forward sweep (250 FCT steps, per-step on-device assembly of the drift matrices),
-cost functional, adjoint sweep (250 FCT steps), descent direction (251 Chebyshev solves).
-Inputs (control, initial condition, target) are resident in HBM before the timed region.
-metric = FCT timesteps (forward + adjoint) per second, whole job.
+Workload (BASELINE.json configs[1], "C2" of SURVEY.md 8d): solid-body rotation + drift control on
+[-1,1]^2, 81x81 P1 nodes (dx = 0.025, n = 6561), dt = 1e-3, T = 0.25 (250 steps), eps = 0, rotation
+(-y,x)*40/pi, drift b = (1,1), slotted-disc initial condition.  One bench "step" = one cost +
+gradient evaluation of the projected-gradient loop: forward sweep (250 FCT steps, on-device assembly
+of the drift matrices), cost functional, adjoint sweep (250 FCT steps), descent direction (251
+Chebyshev solves).  Inputs (control, initial condition, target) are resident in HBM before the timed
+region.  metric = FCT timesteps (forward + adjoint) per second, whole job.
 
 N > 1: every rank runs the same sweep for its own regularisation value beta (config C5:
-embarrassingly parallel), and the ranks all-gather their cost values over RCCL once per
-step; "scaling": "weak".
+embarrassingly parallel) and the ranks all-gather their cost values over RCCL once per step;
+"scaling": "weak".
 
 Extra objects in the JSON line:
-  roofline      HBM roofline of the dominant kernel (Chebyshev/SpMV step), measured on a
-                large synthetic mesh (n = 2049^2: the C2 working set is cache resident)
-                with HIP events on the library's stream; all step kernels in "kernels".
-  cpu_baseline  the CPU oracle (reference-faithful NumPy/SciPy restatement, SuperLU) timed
-                on this host, 1 core, on a bounded sample of the same workload.
+  roofline      HBM roofline of the dominant kernel on a large synthetic mesh (n = 2049^2: the C2
+                working set is cache resident), timed live with HIP events on the library's stream.
+                `achieved`/`frac` price the COMPULSORY bytes of a launch as executed (every array the
+                launch touches counted once: the matrix once per multi-sweep launch) -- <= 1 by
+                construction.  `one_sweep_equiv_GBps` is the figure of the textbook one-sweep
+                formulation (matrix streamed once per sweep), which temporal blocking
+                beats.  `traffic` = PMC-measured bytes per launch from profiles/traffic.json, used
+                only when that file was produced from the same kernel sources (source_sha16).
+                `one_sweep_kernels`: the same sweep with the fusions off -- the SpMV-type and
+                limiter kernels of the north star, one matrix stream per launch.
+  cpu_baseline  the CPU oracle (reference-faithful NumPy/SciPy restatement, SuperLU) timed on this
+                host, 1 core, on a bounded sample of the same workload.
+  parity        GPU trajectories of the timed run against the oracle's on the same inputs
+                (relative l2, tolerance 1e-6 = BASELINE north star).
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,19 +52,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s is achievable by a copy kernel)
 
-# compulsory HBM bytes per matrix row and launch of each step kernel (ELL width 7, float64
-# values, int32 column indices for the 6 off-diagonal slots)
-BYTES_PER_ROW = {
-    "build_low": 7 * 8 + 6 * (4 + 1) + 7 * 8 + 7 * 8 + 8 * 4,   # A, cols+tslot, L, D, ml/u/b/x0
-    "jacobi": 7 * 8 + 6 * 4 + 8 * 3,                            # L, cols, b/x_in/x_out
-    "dudt_rhs": 7 * 8 + 6 * 4 + 8 * 5,                          # A, cols, x, M_diag, u_L, r, y1
-    "cheb": 7 * 8 + 6 * 4 + 8 * 4,                              # M, cols, b/y_mid/y_old/y_new
-    "flux": 6 * 8 * 3 + 6 * 4 + 8 * 5,                          # M, D, F(write), cols, u/du/ml/R+/R-
-    "limit": 6 * 8 + 6 * 4 + 8 * 5,                             # F, cols, R+/R-/u_L/ml/out
-    "assemble": 7 * 8 * 3 + 6 * 4 + 8,                          # Ad, Arot, A(write), cols, c
-}
+# ---------------------------------------------------------------------------------------------
+# Compulsory HBM bytes per matrix row of ONE LAUNCH as executed (float64 values; structured mesh in
+# vertex order: index-free addressing, no column-index bytes; ELL width 7 = diagonal + 6).  Every
+# array a launch reads or writes is counted once, whatever the number of sweeps it performs.
+# ---------------------------------------------------------------------------------------------
+def launch_bytes_per_row(fused: bool, geom_mass: bool):
+    b = {
+        "assemble": 7 * 8 * 3 + 6 * 4 + 8,          # Ad, Arot, A(write), neighbour indices, c   (per level)
+        "build_low": 7 * 8 * 3 + 8 * 4,             # A, L(w), D(w), ml, u_n, b(w), x0(w)
+        "jacobi": 7 * 8 + 8 * 3,                    # L, b, x_in, x_out(w)
+        "dudt_rhs": 7 * 8 + 8 * 5,                  # A, u_L, M_diag, r(w), u_L copy(w), y1(w)
+    }
+    if fused:
+        b["cheb"] = 8 * 4 + (0 if geom_mass else 7 * 8)            # b, y_mid, y_old|y_old(w), y_new(w) [+ M]
+        b["flux"] = 6 * 8 + 8 * 4 + (0 if geom_mass else 6 * 8)     # D, u_L, du, ml, u_out(w) [+ M]: F never stored
+    else:
+        b["cheb"] = 7 * 8 + 8 * 4                                   # M, b, y_mid, y_old, y_new(w)
+        b["flux"] = 6 * 8 * 3 + 8 * 5                               # M, D, F(w), u_L, du, ml, R+(w), R-(w)
+        b["limit"] = 6 * 8 + 8 * 5                                  # F, R+, R-, u_L, ml, u_out(w)
+    return b
+
+
+# one-sweep formulation (what SURVEY.md 8d prices): bytes per row and SWEEP / iteration
+ONE_SWEEP_BYTES = {"jacobi": 80, "cheb": 88, "flux": 184 + 88}
+
+
+def source_sha16():
+    """Identity of the kernel sources a libfemfct.so is built from (profiles/traffic.json carries it)."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "fem-fct-pdeco_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "fem-fct-pdeco_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "femfct.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def slotted_disc_ic(a1, a2, deltax, slit=0.05):
@@ -61,15 +100,114 @@ def slotted_disc_ic(a1, a2, deltax, slit=0.05):
     return ((R < 1 / 3) & ((np.abs(X) > slit) | (Y > 0.5))).astype(np.float64).reshape(-1)
 
 
-def synthetic_control(mesh, num_steps, seed=0):
-    """Smooth space-time control in the admissible box [0,5] (synthetic data)."""
-    x, y = mesh.coordinates()
-    v2d = mesh.vertex_to_dof
+def synthetic_control(x, y, v2d, num_steps):
+    """Smooth space-time control in the admissible box [0,5] (synthetic data), FEniCS DoF order."""
     t = np.linspace(0.0, 1.0, num_steps + 1)[:, None]
     c = 1.5 + 1.0 * np.sin(2 * np.pi * (x[None, :] + t)) * np.cos(np.pi * y[None, :]) + 0.5 * t
     out = np.empty_like(c)
     out[:, v2d] = c
     return np.clip(out, 0.0, 5.0).reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-rank plumbing (kept in small functions so that the gloo CPU test drives the same code)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(argv, n_ranks):
+    """Start ``python -m torch.distributed.run`` with n_ranks ranks of this script as a CHILD process (nothing
+    in this process has touched the GPU yet), relay its output, return its exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+class Ranks:
+    """The three things the timed region needs from torch.distributed: the all-gather of the cost
+    scalars, the barrier-bracketed fence and the max-over-ranks of the elapsed time."""
+
+    def __init__(self, world, rank, local_rank, backend):
+        self.world, self.rank, self.local_rank, self.backend = world, rank, local_rank, backend
+        self.dist = None
+        self.torch = None
+        if world > 1 or backend == "nccl":
+            import torch
+            self.torch = torch
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if backend == "nccl":                                   # RCCL on ROCm
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+        self.device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+
+    def gather_costs(self, J):
+        """the sweep's only exchange: one all-gather of 8 bytes per rank"""
+        if self.dist is None:
+            return [float(J)]
+        t = self.torch.tensor([float(J)], dtype=self.torch.float64, device=self.device)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def fence(self, sync_device):
+        sync_device()
+        if self.backend == "nccl":
+            self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
+
+    def max_elapsed(self, elapsed):
+        if self.dist is None:
+            return elapsed
+        t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+class StubProblem:
+    """--stub-solver: stands in for the GPU problem so that the N > 1 control flow (self-launch, rendezvous,
+    all-gather, barriers, max-over-ranks, rank-0 JSON) runs on a CPU box under gloo.  Its numbers mean nothing."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def one_step(self, beta):
+        time.sleep(0.01 * (1 + self.rank))
+        return 100.0 + self.rank + beta
+
+    def synchronize(self):
+        pass
 
 
 def main():
@@ -81,93 +219,81 @@ def main():
     ap.add_argument("--roofline-cells", type=int, default=2048, help="cells per side of the roofline mesh (0: skip)")
     ap.add_argument("--roofline-steps", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=250,
-                    help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~8 s of one core (0: skip)")
+                    help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~10 s of one core (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
     ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
+    ap.add_argument("--stub-solver", action="store_true",
+                    help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no library); not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ranks = Ranks(world, rank, local_rank, "gloo" if args.stub_solver else "nccl")
 
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
-
-    hp = importlib.import_module("fem-fct-pdeco_amd")
-    solvers = importlib.import_module("fem-fct-pdeco_amd.solvers")
-    hp.fct_helpers.VERBOSE = False
-
-    # ------------------------------------------------------------ workload C2
+    betas = [10.0 ** (-k / 2) for k in range(8)]          # C5 sweep values
+    beta = betas[rank % len(betas)] if world > 1 else 1.0  # C2: beta = 1
     a1, a2, deltax, dt, T = -1.0, 1.0, 0.1 / 2 / 2, 0.001, 0.25
     n_cells = round((a2 - a1) / deltax)
     Nt = round(T / dt)
     om = np.pi / 40
     B = args.batch
-    mesh = hp.SquareMeshP1(a1, a2, n_cells)
-    n = mesh.nodes
-    tl = (Nt + 1) * n
-    betas = [10.0 ** (-k / 2) for k in range(8)]          # C5 sweep values
-    beta = betas[rank % len(betas)] if world > 1 else 1.0  # C2: beta = 1
-    # device arrays live in dolfin vertex order (the library's fast layout: index-free stencil
-    # addressing + 2-D tile kernels); the DoF-ordered arrays below feed the CPU oracle
-    prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=local_rank,
-                                  order=hp.ORDER_VERTEX)
-    ctx = prob.ctx
-    to_dev = lambda x: hp.reorder_vector_from_dof(x, x.size // n, n, mesh.vertex_to_dof)
-    u0 = hp.reorder_vector_to_dof(slotted_disc_ic(a1, a2, deltax), 1, n, mesh.vertex_to_dof)
-    ck = synthetic_control(mesh, Nt, seed=rank)
-    gpath = os.path.join(ROOT, "tests", "golden", "solidbody_t0.25_u.npz")
-    uhat = np.load(gpath)["u"] if os.path.exists(gpath) else np.roll(u0, 7)
-    init = np.zeros((B, tl))
-    init[:, :n] = u0
-    init[:, :n] = to_dev(u0)
-    d_c = ctx.array(np.tile(to_dev(ck), B))
-    d_u = ctx.array(init.reshape(-1))
-    d_p = ctx.zeros(B * tl)
-    d_d = ctx.zeros(tl)
-    d_rhs = ctx.empty(tl)
-    d_uhat = ctx.array(np.tile(to_dev(uhat), B))
 
-    def one_step():
-        prob.forward(d_c, d_u, batch=B)
-        J = prob.cost(d_u, d_uhat, d_c, beta, "finaltime", batch=B)
-        prob.adjoint(d_c, d_u, d_uhat, d_p, "finaltime", batch=B)
-        prob.descent_direction(d_c, d_u, d_p, beta, d_d, scratch=d_rhs)   # batch member 0 (one control)
-        if dist is not None:
-            t_j = torch.tensor([float(J[0])], dtype=torch.float64, device=f"cuda:{local_rank}")
-            out = [torch.empty_like(t_j) for _ in range(world)]
-            dist.all_gather(out, t_j)                                     # RCCL: the sweep's only exchange
-            return [float(o.item()) for o in out]
-        return [float(J[0])]
+    if args.stub_solver:
+        stub = StubProblem(rank)
+        one_step = lambda: ranks.gather_costs(stub.one_step(beta))
+        sync = stub.synchronize
+        n = (n_cells + 1) ** 2
+    else:
+        hp = importlib.import_module("fem-fct-pdeco_amd")
+        solvers = importlib.import_module("fem-fct-pdeco_amd.solvers")
+        hp.fct_helpers.VERBOSE = False
+        mesh = hp.SquareMeshP1(a1, a2, n_cells)
+        n = mesh.nodes
+        tl = (Nt + 1) * n
+        # device arrays live in dolfin vertex order (the library's fast layout: index-free stencil
+        # addressing + 2-D tile kernels); the DoF-ordered arrays below feed the CPU oracle
+        prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=local_rank,
+                                      order=hp.ORDER_VERTEX)
+        ctx = prob.ctx
+        to_dev = lambda x: hp.reorder_vector_from_dof(x, x.size // n, n, mesh.vertex_to_dof)
+        from_dev = lambda x: hp.reorder_vector_to_dof(x, x.size // n, n, mesh.vertex_to_dof)
+        u0 = hp.reorder_vector_to_dof(slotted_disc_ic(a1, a2, deltax), 1, n, mesh.vertex_to_dof)
+        xs, ys = mesh.coordinates()
+        ck = synthetic_control(xs, ys, mesh.vertex_to_dof, Nt)
+        gpath = os.path.join(ROOT, "tests", "golden", "solidbody_t0.25_u.npz")
+        uhat = np.load(gpath)["u"] if os.path.exists(gpath) else np.roll(u0, 7)
+        init = np.zeros((B, tl))
+        init[:, :n] = to_dev(u0)
+        d_c = ctx.array(np.tile(to_dev(ck), B))
+        d_u = ctx.array(init.reshape(-1))
+        d_p = ctx.zeros(B * tl)
+        d_d = ctx.zeros(tl)
+        d_rhs = ctx.empty(tl)
+        d_uhat = ctx.array(np.tile(to_dev(uhat), B))
+        sync = ctx.synchronize
 
-    def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        def one_step():
+            prob.forward(d_c, d_u, batch=B)
+            J = prob.cost(d_u, d_uhat, d_c, beta, "finaltime", batch=B)
+            prob.adjoint(d_c, d_u, d_uhat, d_p, "finaltime", batch=B)
+            prob.descent_direction(d_c, d_u, d_p, beta, d_d, scratch=d_rhs)   # batch member 0 (one control)
+            return ranks.gather_costs(J[0])
 
     for _ in range(args.warmup):
         one_step()
-    fence()
+    ranks.fence(sync)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         Js = one_step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t_el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        elapsed = float(t_el.item())
-    log = prob.solver_log(B)
-    fct_steps_per_bench_step = 2 * Nt * B * world
-    value = fct_steps_per_bench_step * args.steps / elapsed
+    ranks.fence(sync)
+    elapsed = ranks.max_elapsed(time.perf_counter() - t0)
+    value = 2 * Nt * B * world * args.steps / elapsed
 
     result = {
         "metric": "FCT timesteps/sec (fwd+adj)", "value": value, "unit": "timesteps/s",
@@ -177,11 +303,21 @@ def main():
         "config": {"workload": "C2 advection_solidbody_FCT_PDECO_finaltime: [-1,1]^2 81x81 P1 (dx=0.025, n=6561), "
                                "dt=1e-3, 250 fwd + 250 adj FCT steps per cost+gradient evaluation",
                    "nodes": n, "num_steps": Nt, "dt": dt, "batch_per_gpu": B,
-                   "parallelism": f"beta-sweep x{world}" if world > 1 else "single trajectory",
-                   "low_order_solver": "jacobi", "jacobi_sweeps_max": int(log["solver_iters"].max()),
-                   "solver_resid_max": float(log["solver_resid"].max()), "graphs": True},
-        "cost": Js[0],
+                   "parallelism": f"beta-sweep x{world}" if world > 1 else "single trajectory"},
+        "cost": Js[0], "costs_all_ranks": Js if world > 1 else None,
     }
+    if args.stub_solver:
+        result["stub"] = True
+        result["data"] = "stub (control-flow rehearsal, not a measurement)"
+        ranks.close()
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return
+
+    log = prob.solver_log(B)
+    result["config"].update({"low_order_solver": "jacobi", "jacobi_sweeps_max": int(log["solver_iters"].max()),
+                             "solver_resid_max": float(log["solver_resid"].max()), "graphs": True,
+                             "kernel_regime": int(ctx.kernel_regime(B)), "source_sha16": source_sha16()})
 
     # ---------------------------------------------------- per-kernel timing at C2 size
     if rank == 0:
@@ -236,21 +372,60 @@ def main():
         pg["cost_rel_diff"] = abs(pg["speculative"]["cost"] - pg["sequential"]["cost"]) / abs(pg["sequential"]["cost"])
         result["pgd_c2"] = pg
     if rank == 0 and world == 1 and args.cpu_sample > 0:      # the CPU baseline is an N = 1 figure
-        result["cpu_baseline"] = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # what the timed region left in HBM: batch member 0's state and adjoint trajectories for the control ck
+        gpu_u = from_dev(d_u.download()[:tl])
+        gpu_p = from_dev(d_p.download()[:tl])
+        base, par = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample, gpu_u, gpu_p)
+        result["cpu_baseline"] = base
+        result["parity"] = par
+    ranks.close()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+
+
+def _profiled_forward(prob, ctx, d_c, d_u, steps):
+    for _ in range(6):                         # warm-up: the sweep budget / launch plan settles (one trial of
+        prob.forward(d_c, d_u, batch=1)        # fewer launches may fail and repeat a sweep on the way)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    prob.forward(d_c, d_u, batch=1)            # graph replay, un-profiled: whole-step time
+    ctx.synchronize()
+    step_ms = 1e3 * (time.perf_counter() - t0) / steps
+    ctx.set_profiling(True)
+    prob.forward(d_c, d_u, batch=1)
+    rep = ctx.profile_report()
+    ctx.set_profiling(False)
+    log = prob.solver_log(1)
+    return step_ms, rep, int(log["solver_iters"].sum())
+
+
+def _kernel_table(rep, bpr, n, units, traffic, one_sweep_units):
+    """Per kernel class: compulsory bytes of a launch as executed / measured launch time."""
+    kernels = {}
+    for k, (ms, cnt) in rep.items():
+        if not cnt or k not in bpr:
+            continue
+        per_launch = bpr[k] * n * (units.get(k, cnt) / cnt if k == "assemble" else 1.0)
+        avg_ms = ms / cnt
+        e = {"launches": cnt, "avg_launch_ms": avg_ms, "total_ms": ms,
+             "compulsory_bytes_per_row_per_launch": per_launch / n,
+             "achieved_GBps": per_launch / (1e6 * avg_ms), "frac": per_launch / (1e6 * avg_ms) / HBM_PEAK_GBS}
+        if k in one_sweep_units and k in ONE_SWEEP_BYTES:
+            e["sweeps_per_launch"] = one_sweep_units[k] / cnt
+            e["one_sweep_equiv_GBps"] = ONE_SWEEP_BYTES[k] * n * one_sweep_units[k] / (1e6 * ms)
+        if traffic and k in traffic:
+            e["traffic_bytes_per_launch"] = traffic[k]
+            e["traffic_bytes_per_row"] = traffic[k] / n
+            # FETCH_SIZE counts Infinity-Cache hits as well (MI355X_MICROARCH.md, HBM): an upper bound on HBM bytes
+            e["traffic_frac_incl_infinity_cache"] = traffic[k] / (1e6 * avg_ms) / HBM_PEAK_GBS
+            e["overfetch"] = traffic[k] / per_launch
+        kernels[k] = e
+    return kernels
 
 
 def roofline(hp, solvers, n_cells, steps, device_id):
-    """HBM roofline on a mesh far larger than L2 + Infinity Cache (per-class HIP-event timing of
-    one forward sweep).  `achieved` follows the contract: algorithmic bytes of the work a launch
-    performs (bytes/row of the one-sweep formulation x rows x sweeps in the launch) / launch time.
-    The tile-fused Jacobi/Chebyshev kernels run 8 sweeps per pass over the matrix, so their real
-    HBM traffic (`traffic`, from rocprofv3 PMC passes) is far below the algorithmic figure and
-    `frac` can exceed 1; `hbm_frac` = traffic / time / peak is the physical utilisation."""
+    """HBM roofline on a mesh far larger than L2 + Infinity Cache: per-class HIP-event timing of one forward
+    sweep (events recorded on the library's own stream around every launch)."""
     a1, a2 = -1.0, 1.0
     h = (a2 - a1) / n_cells
     dt = 1e-3 * h / 0.025                      # same CFL number as C2
@@ -266,60 +441,82 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     init = np.zeros((steps + 1) * n)
     init[:n] = u0
     d_u = ctx.array(init)
-    for _ in range(6):                         # warm-up: the sweep budget / launch plan settles (one trial of
-        prob.forward(d_c, d_u, batch=1)        # fewer launches may fail and repeat a sweep on the way)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    prob.forward(d_c, d_u, batch=1)            # graph replay, un-profiled: whole-step time
-    ctx.synchronize()
-    step_ms = 1e3 * (time.perf_counter() - t0) / steps
-    ctx.set_profiling(True)
-    prob.forward(d_c, d_u, batch=1)
-    rep = ctx.profile_report()
-    ctx.set_profiling(False)
-    log = prob.solver_log(1)
-    sweeps = int(log["solver_iters"].sum())
-    # sweeps / iterations / levels actually executed (the operators of all levels are assembled in one launch)
-    units = {"jacobi": sweeps, "cheb": 19 * steps, "assemble": steps}
-    fused_flux = rep["limit"][1] == 0                       # flux + limit in one launch
-    bpr = dict(BYTES_PER_ROW)
-    if fused_flux:
-        bpr["flux"] = BYTES_PER_ROW["flux"] + BYTES_PER_ROW["limit"]
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch
-    tr = json.load(open(tpath)).get(f"n{n}", {}) if os.path.exists(tpath) else {}
-    kernels = {}
-    for k, (ms, cnt) in rep.items():
-        if not cnt or k not in bpr:
-            continue
-        u = units.get(k, cnt)
-        alg = bpr[k] * n * u
-        e = {"total_ms": ms, "launches": cnt, "avg_launch_ms": ms / cnt, "sweeps_per_launch": u / cnt,
-             "bytes_per_row_per_sweep": bpr[k], "achieved_GBps": alg / (1e6 * ms), "frac": alg / (1e6 * ms) / HBM_PEAK_GBS}
-        if k in tr:
-            e["traffic_bytes_per_launch"] = tr[k]
-            e["hbm_frac"] = tr[k] / (1e6 * ms / cnt) / HBM_PEAK_GBS
-        kernels[k] = e
+    regime = int(ctx.kernel_regime(1))
+    geom = os.environ.get("FEMFCT_GEOM_MASS", "1") != "0"
+    sha = source_sha16()
+
+    # PMC-derived HBM bytes per launch: only when measured on this very source tree (tools/refresh_profiles.sh)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic, traffic_note = None, "profiles/traffic.json absent"
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        ent = tj.get(f"n{n}")
+        if ent is None:
+            traffic_note = f"no PMC record for n={n}"
+        elif ent.get("source_sha16") != sha:
+            traffic_note = (f"PMC record is from kernel sources {ent.get('source_sha16')}, this build is {sha}: "
+                            "omitted (re-run tools/refresh_profiles.sh)")
+        else:
+            traffic, traffic_note = ent["bytes_per_launch"], f"rocprofv3 PMC passes, source_sha16 {sha}"
+
+    # ---- (1) the product path at this size (fused multi-sweep kernels)
+    step_ms, rep, sweeps = _profiled_forward(prob, ctx, d_c, d_u, steps)
+    fused_flux = rep["limit"][1] == 0
+    bpr = launch_bytes_per_row(fused=regime >= 2 and fused_flux, geom_mass=geom)
+    units = {"assemble": steps}
+    one_sweep_units = {"jacobi": sweeps, "cheb": 19 * steps, "flux": steps}
+    kernels = _kernel_table(rep, bpr, n, units, traffic, one_sweep_units)
+    step_bytes = sum(e["compulsory_bytes_per_row_per_launch"] * n * e["launches"] for e in kernels.values()) / steps
+    step_traffic = (sum(e["traffic_bytes_per_launch"] * e["launches"] for e in kernels.values()
+                        if "traffic_bytes_per_launch" in e) / steps) if traffic else None
     dom_name = max(("jacobi", "cheb"), key=lambda k: kernels[k]["total_ms"])
     dom = kernels[dom_name]
-    if dom["sweeps_per_launch"] > 1.5:
-        sym = {"jacobi": "k_strip4_jacobi<0>", "cheb": "k_strip4_cheb"}[dom_name] if n >= 90000 else \
-              {"jacobi": "k_tile_jacobi<H,0,0>", "cheb": "k_tile_cheb<H>"}[dom_name]
-        label = f"{sym} (tile-fused, {dom['sweeps_per_launch']:.1f} sweeps per launch)"
-    else:
-        label = {"jacobi": "k_jacobi<7,256,*>", "cheb": "k_cheb<7,256,*>"}[dom_name] + " (one sweep per launch)"
-    out = {"bound": "hbm", "kernel": label,
+    sym = {3: {"jacobi": "k_strip4_jacobi<0>", "cheb": "k_strip4_cheb_mass" if geom else "k_strip4_cheb"},
+           2: {"jacobi": "k_tile_jacobi<H,0,BIG>", "cheb": "k_tile_cheb<H>"},
+           1: {"jacobi": "k_strip_jacobi<RPT>", "cheb": "k_strip_cheb<RPT>"},
+           0: {"jacobi": "k_jacobi<7,256,1>", "cheb": "k_cheb<7,256,1>"}}[regime][dom_name]
+    out = {"bound": "hbm", "kernel": f"{sym} ({dom.get('sweeps_per_launch', 1):.1f} sweeps per launch)",
            "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
-           "traffic": dom.get("traffic_bytes_per_launch"), "hbm_frac": dom.get("hbm_frac"),
+           "traffic": dom.get("traffic_bytes_per_launch"), "traffic_source": traffic_note,
+           "traffic_frac_incl_infinity_cache": dom.get("traffic_frac_incl_infinity_cache"),
+           "one_sweep_equiv_GBps": dom.get("one_sweep_equiv_GBps"),
+           "definition": "achieved = compulsory bytes of one launch as executed (each array once; L once per "
+                         "multi-sweep launch) / mean launch time by HIP events; frac = achieved / 8 TB/s",
            "workload": f"synthetic square mesh {n_cells + 1}x{n_cells + 1} (n={n}), vertex order, same CFL as C2",
-           "algorithmic_bytes_per_launch": dom["bytes_per_row_per_sweep"] * n * dom["sweeps_per_launch"],
-           "avg_launch_ms": dom["avg_launch_ms"], "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms,
-           "jacobi_sweeps_per_step": sweeps / steps, "kernels": kernels}
+           "compulsory_bytes_per_launch": dom["compulsory_bytes_per_row_per_launch"] * n,
+           "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "source_sha16": sha,
+           "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms, "jacobi_sweeps_per_step": sweeps / steps,
+           "step": {"compulsory_bytes": step_bytes, "compulsory_GBps": step_bytes / (1e6 * step_ms),
+                    "compulsory_frac": step_bytes / (1e6 * step_ms) / HBM_PEAK_GBS,
+                    "traffic_bytes": step_traffic,
+                    "traffic_frac_incl_infinity_cache": (step_traffic / (1e6 * step_ms) / HBM_PEAK_GBS) if step_traffic else None},
+           "kernels": kernels}
+
+    # ---- (2) fusions off: the one-sweep SpMV-type (Jacobi / Chebyshev) and limiter kernels of the north star
+    ctx.set_fusion(False, False)
+    step1_ms, rep1, sweeps1 = _profiled_forward(prob, ctx, d_c, d_u, steps)
+    bpr1 = launch_bytes_per_row(fused=False, geom_mass=False)
+    k1 = {}
+    for k, (ms, cnt) in rep1.items():
+        if not cnt or k not in bpr1:
+            continue
+        # launches enqueued after the device-side convergence test has passed return at once: price the sweeps
+        # that ran, over the time of all launches (conservative)
+        ran = sweeps1 if k == "jacobi" else (steps if k == "assemble" else cnt)
+        by = bpr1[k] * n * ran
+        k1[k] = {"launches": cnt, "executed": ran, "total_ms": ms, "compulsory_bytes_per_row_per_launch": bpr1[k],
+                 "achieved_GBps": by / (1e6 * ms), "frac": by / (1e6 * ms) / HBM_PEAK_GBS}
+    out["one_sweep_kernels"] = {"fct_step_ms": step1_ms, "fct_steps_per_s": 1e3 / step1_ms,
+                                "jacobi_sweeps_per_step": sweeps1 / steps, "kernels": k1,
+                                "note": "femfct_set_fusion(0, 0): k_jacobi / k_cheb (SpMV-type) and k_flux + k_limit, "
+                                        "one matrix stream per launch"}
     prob.close()
     return out
 
 
-def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample):
-    """CPU oracle (test infrastructure) timed on this host as the reported CPU baseline."""
+def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, gpu_p=None):
+    """CPU oracle (test infrastructure) timed on this host as the reported CPU baseline, and -- the oracle being
+    the checker -- compared with the GPU trajectories the timed region produced for the same inputs."""
     from oracle.mesh import SquareMesh
     from oracle.assembly import P1Assembler
     from oracle import traj as otraj, fct as ofct
@@ -341,6 +538,16 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample):
     pk = np.zeros_like(uk)
     otraj.solidbody_adjoint(sb, c, uk, uhat, pk, n, ns, dt, optim="finaltime")
     t_vec = time.perf_counter() - t0
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    parity = None
+    if gpu_u is not None:
+        m = (ns + 1) * n
+        parity = {"u_rel_l2": rel(gpu_u[:m], uk), "u_final_rel_l2": rel(gpu_u[ns * n:m], uk[ns * n:]),
+                  "p_rel_l2": rel(gpu_p[:m], pk) if ns == Nt else None, "tol": 1e-6,
+                  "levels_compared": ns + 1,
+                  "what": "GPU state/adjoint trajectories of the timed C2 run vs the CPU oracle on the same control, "
+                          "initial condition and target (81x81, dt 1e-3)"}
+        parity["ok"] = bool(parity["u_rel_l2"] < 1e-6 and (parity["p_rel_l2"] is None or parity["p_rel_l2"] < 1e-6))
     # reference-cost-profile variant (LIL + interpreter loops, the reference's data structures)
     nb = mesh.dof_neighbors()
     A = -(sb.A_u(c[n:2 * n]))
@@ -349,15 +556,16 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample):
     for _ in range(reps):
         ofct.fct_step_lil(A, np.zeros(n), u0, dt, n, sb.cm.M, sb.cm.ML, nb)
     t_lil = (time.perf_counter() - t1) / reps
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
-    return {"value": 2 * ns / t_vec, "unit": "timesteps/s", "cores": 1, "kind": "port",
+    if limiter is not None and hasattr(limiter, "unregister"):
+        limiter.unregister()
+    base = {"value": 2 * ns / t_vec, "unit": "timesteps/s", "cores": 1, "kind": "port",
             "sample": f"{ns} forward + {ns} adjoint FCT steps of the C2 workload (per-step assembly + "
                       f"vectorised NumPy/SciPy FCT step with SuperLU), 1 thread",
             "host_cpus": os.cpu_count(),
             "reference_profile_variant": {"value": 1.0 / t_lil, "unit": "timesteps/s",
                                           "sample": f"{reps} FCT steps with LIL matrices + Python loops "
                                                     "(the reference's data structures), no assembly"}}
+    return base, parity
 
 
 if __name__ == "__main__":

@@ -17,7 +17,8 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_NOMEM = 0, 1, 2, 3, 4
 FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV = 1, 2, 4, 8
 ORDER_VERTEX, ORDER_FENICS = 0, 1
 SOLVER_JACOBI, SOLVER_BICGSTAB = 0, 1
-ABI_VERSION = 2
+REGIME_ROWS, REGIME_STRIPS, REGIME_TILE32, REGIME_PATCH64 = 0, 1, 2, 3
+ABI_VERSION = 3
 
 
 class FemFctError(RuntimeError):
@@ -71,6 +72,7 @@ SIGNATURES = {
     "femfct_set_solver": (C.c_int, [_p, C.c_int, _d, C.c_int]),
     "femfct_set_graphs": (C.c_int, [_p, C.c_int]),
     "femfct_set_fusion": (C.c_int, [_p, C.c_int, C.c_int]),
+    "femfct_kernel_regime": (C.c_int, [_p, _i]),
     "femfct_set_profiling": (C.c_int, [_p, C.c_int]),
     "femfct_profile_report": (C.c_int, [_p, _p, _p, _i]),
     "femfct_malloc": (C.c_int, [_p, C.POINTER(_p), C.c_size_t]),

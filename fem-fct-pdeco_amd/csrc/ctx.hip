@@ -296,6 +296,7 @@ int femfct_destroy(femfct_ctx* ctx) {
 const char* femfct_last_error(const femfct_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int femfct_synchronize(femfct_ctx* ctx) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FEMFCT_OK;
@@ -304,6 +305,7 @@ int femfct_synchronize(femfct_ctx* ctx) {
 void* femfct_stream(femfct_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     ARG_TRY(ctx, solver == FEMFCT_SOLVER_JACOBI || solver == FEMFCT_SOLVER_BICGSTAB, "unknown solver");
     ARG_TRY(ctx, rel_tol > 0 && rel_tol < 1 && max_iters >= 1, "bad tolerance / iteration cap");
@@ -317,6 +319,7 @@ int femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters
 }
 
 int femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->use_strips = strips != 0;
@@ -327,7 +330,20 @@ int femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles) {
     return FEMFCT_OK;
 }
 
+// which family of Jacobi / Chebyshev kernels a step with `batch` members runs (tests assert that a size class really
+// exercises the kernels it is meant to cover; bench.py labels its roofline record with it)
+int femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch) {
+    if (!ctx || ctx->n <= 0) return -1;
+    if (femfct_tile4_wanted(ctx, batch)) return FEMFCT_REGIME_PATCH64;
+    TilePlan tp;
+    if (ctx->use_strips && femfct_tile_plan(ctx, &tp, true, 0, batch)) return FEMFCT_REGIME_TILE32;
+    StripPlan sp;
+    if (femfct_strip_plan(ctx, &sp)) return FEMFCT_REGIME_STRIPS;
+    return FEMFCT_REGIME_ROWS;
+}
+
 int femfct_set_graphs(femfct_ctx* ctx, int enable) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     ctx->use_graphs = enable != 0;
     if (!enable) femfct_drop_graphs(ctx);
@@ -337,6 +353,7 @@ int femfct_set_graphs(femfct_ctx* ctx, int enable) {
 // per-kernel timing with HIP events on the ctx stream.  Profiling forces eager launches
 // (graphs off) while enabled.
 int femfct_set_profiling(femfct_ctx* ctx, int enable) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& r : ctx->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -346,6 +363,7 @@ int femfct_set_profiling(femfct_ctx* ctx, int enable) {
 }
 
 int femfct_profile_report(femfct_ctx* ctx, double* total_ms_host, int32_t* launches_host, int32_t n_classes) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && total_ms_host && launches_host && n_classes >= KC_COUNT, "need >= 8 classes");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < n_classes; ++k) { total_ms_host[k] = 0.0; launches_host[k] = 0; }
@@ -364,6 +382,7 @@ int femfct_profile_report(femfct_ctx* ctx, double* total_ms_host, int32_t* launc
 
 // ----------------------------------------------------------------- memory
 int femfct_malloc(femfct_ctx* ctx, void** dev_ptr, size_t bytes) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && dev_ptr, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(dev_ptr, bytes ? bytes : 8);
@@ -371,29 +390,34 @@ int femfct_malloc(femfct_ctx* ctx, void** dev_ptr, size_t bytes) {
     return FEMFCT_OK;
 }
 int femfct_free(femfct_ctx* ctx, void* p) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(p));
     return FEMFCT_OK;
 }
 int femfct_memcpy_h2d(femfct_ctx* ctx, void* d, const void* h, size_t bytes) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && (bytes == 0 || (d && h)), "null argument");
     HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FEMFCT_OK;
 }
 int femfct_memcpy_d2h(femfct_ctx* ctx, void* h, const void* d, size_t bytes) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && (bytes == 0 || (d && h)), "null argument");
     HIP_TRY(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FEMFCT_OK;
 }
 int femfct_memcpy_d2d(femfct_ctx* ctx, void* d, const void* s, size_t bytes) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && (bytes == 0 || (d && s)), "null argument");
     HIP_TRY(ctx, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return FEMFCT_OK;
 }
 int femfct_memset0(femfct_ctx* ctx, void* d, size_t bytes) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && (bytes == 0 || d), "null argument");
     HIP_TRY(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
     return FEMFCT_OK;
@@ -401,6 +425,7 @@ int femfct_memset0(femfct_ctx* ctx, void* d, size_t bytes) {
 
 // ---------------------------------------------------------------- pattern
 int femfct_set_pattern_csr(femfct_ctx* ctx, int32_t n, const int32_t* indptr, const int32_t* indices) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && indptr && indices && n > 0, "null/empty pattern");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -457,6 +482,7 @@ int32_t femfct_n(const femfct_ctx* ctx) { return ctx ? ctx->n : 0; }
 int32_t femfct_ell_width(const femfct_ctx* ctx) { return ctx ? ctx->W : 0; }
 
 int femfct_get_ell_cols(femfct_ctx* ctx, int32_t* cols_host) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && cols_host && ctx->n > 0, "no pattern");
     memcpy(cols_host, ctx->h_cols.data(), sizeof(int32_t) * ctx->h_cols.size());
     return FEMFCT_OK;
@@ -475,6 +501,7 @@ static int need_csr_map(femfct_ctx* ctx) {
 }
 
 int femfct_csr_to_ell(femfct_ctx* ctx, const double* csr_vals_host, double* ell_dev) {
+    FEMFCT_ENTER(ctx);
     int rc = need_csr_map(ctx);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, csr_vals_host && ell_dev, "null argument");
@@ -488,6 +515,7 @@ int femfct_csr_to_ell(femfct_ctx* ctx, const double* csr_vals_host, double* ell_
 }
 
 int femfct_ell_to_csr(femfct_ctx* ctx, const double* ell_dev, double* csr_vals_host) {
+    FEMFCT_ENTER(ctx);
     int rc = need_csr_map(ctx);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, csr_vals_host && ell_dev, "null argument");
@@ -500,6 +528,7 @@ int femfct_ell_to_csr(femfct_ctx* ctx, const double* ell_dev, double* csr_vals_h
 }
 
 int femfct_set_mass(femfct_ctx* ctx, const double* M_csr_vals_host, const double* ml_host) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0, "no pattern registered");
     ARG_TRY(ctx, M_csr_vals_host && ml_host, "null argument");
     int rc = femfct_csr_to_ell(ctx, M_csr_vals_host, ctx->d_M);
@@ -528,6 +557,7 @@ static int launch_step(femfct_ctx* ctx, const double* A, const double* N, int32_
 
 int femfct_fct_step(femfct_ctx* ctx, const double* A_ell, const double* N_ell, int32_t N_shared, const double* rhs,
                     const double* u_n, double dt, double* u_out, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0, "no pattern registered");
     ARG_TRY(ctx, ctx->have_mass, "mass matrix not set (femfct_set_mass / femfct_set_mesh_square)");
     ARG_TRY(ctx, A_ell && u_n && u_out, "null argument");
@@ -538,6 +568,7 @@ int femfct_fct_step(femfct_ctx* ctx, const double* A_ell, const double* N_ell, i
 }
 
 int femfct_last_step_info(femfct_ctx* ctx, femfct_step_info* info, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && info && batch >= 1 && batch <= ctx->ws_batch, "bad argument");
     std::vector<StepCtl> h(batch);
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_ctl, sizeof(StepCtl) * batch, hipMemcpyDeviceToHost, ctx->stream));
@@ -557,6 +588,7 @@ int femfct_last_step_info(femfct_ctx* ctx, femfct_step_info* info, int32_t batch
 
 int femfct_fct_step_host(femfct_ctx* ctx, const double* A_csr, const double* N_csr, const double* rhs,
                          const double* u_n, double dt, double* u_out, femfct_step_info* info) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0, "no pattern registered");
     ARG_TRY(ctx, A_csr && u_n && u_out, "null argument");
     int rc;
@@ -594,6 +626,7 @@ int femfct_fct_step_host(femfct_ctx* ctx, const double* A_csr, const double* N_c
 
 int femfct_chebsi(femfct_ctx* ctx, const double* b_dev, double* y_dev, int32_t cheb_iter, double lmin, double lmax,
                   int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0 && ctx->have_mass, "mass matrix not set");
     ARG_TRY(ctx, b_dev && y_dev && cheb_iter >= 1 && batch >= 1 && lmin + lmax != 0, "bad argument");
     int rc = femfct_ensure_workspace(ctx, batch);
@@ -602,6 +635,7 @@ int femfct_chebsi(femfct_ctx* ctx, const double* b_dev, double* y_dev, int32_t c
 }
 
 int femfct_artificial_diffusion(femfct_ctx* ctx, const double* K_ell, double* D_ell, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0, "no pattern registered");
     ARG_TRY(ctx, K_ell && D_ell && batch >= 1, "bad argument");
     return femfct_enqueue_artdiff(ctx, K_ell, D_ell, batch);
@@ -609,6 +643,7 @@ int femfct_artificial_diffusion(femfct_ctx* ctx, const double* K_ell, double* D_
 
 int femfct_spmv(femfct_ctx* ctx, const double* mat_ell, const double* x_dev, double alpha, double beta, double* y_dev,
                 int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0, "no pattern registered");
     ARG_TRY(ctx, mat_ell && x_dev && y_dev && batch >= 1, "bad argument");
     return femfct_enqueue_spmv(ctx, mat_ell, x_dev, alpha, beta, y_dev, batch);

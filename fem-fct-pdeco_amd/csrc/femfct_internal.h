@@ -166,6 +166,15 @@ int femfct_fail(femfct_ctx* ctx, int code, const char* fmt, ...);
         if (!(cond)) return femfct_fail((ctx), FEMFCT_ERR_INVALID, "%s", msg);      \
     } while (0)
 
+// First statement of every extern "C" entry point that allocates, copies or launches: HIP's current device is per
+// thread, so a context created on device d must select d on whichever thread calls it (two contexts on different
+// GPUs in one process, or a context used from a thread other than its creator's).
+#define FEMFCT_ENTER(ctx)                                                           \
+    do {                                                                            \
+        if (!(ctx)) return FEMFCT_ERR_INVALID;                                      \
+        HIP_TRY((ctx), hipSetDevice((ctx)->device));                                \
+    } while (0)
+
 int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch);
 int femfct_ensure_krylov_ws(femfct_ctx* ctx, int32_t batch);
 void femfct_drop_graphs(femfct_ctx* ctx);
@@ -209,6 +218,7 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, struct MatRef A, struct VecRe
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch, int* tail_first = nullptr);
 bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch);
+bool femfct_geom_mass(const femfct_ctx* ctx);   // M may be derived from the cell geometry instead of loaded
 int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old,
                                         int k_first, int k_last, const double* omegas, double md_scale, const double* D,
                                         const double* ulow, double dt, struct VecRef out, int64_t out_bstride, int32_t batch,

@@ -268,6 +268,7 @@ int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const dou
 extern "C" {
 
 int femfct_mesh_quad_points(femfct_ctx* ctx, double* xq_host, double* yq_host) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set");
     ARG_TRY(ctx, xq_host && yq_host, "null argument");
     int64_t ntri = (int64_t)ctx->n_cells * ctx->n_cells * 2;
@@ -285,6 +286,7 @@ int femfct_mesh_quad_points(femfct_ctx* ctx, double* xq_host, double* yq_host) {
 }
 
 int femfct_assemble_convection(femfct_ctx* ctx, const double* wind_q_host, double scale, double* A_ell_dev) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set");
     ARG_TRY(ctx, wind_q_host && A_ell_dev, "null argument");
     int64_t cnt = (int64_t)ctx->n_cells * ctx->n_cells * 2 * 6 * 2;
@@ -301,6 +303,7 @@ int femfct_assemble_convection(femfct_ctx* ctx, const double* wind_q_host, doubl
 
 int femfct_drift_gradient_rhs(femfct_ctx* ctx, const double* c_dev, const double* u_dev, const double* p_dev,
                               double beta, double bx, double by, double* out_dev, int32_t levels) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set");
     ARG_TRY(ctx, c_dev && u_dev && p_dev && out_dev && levels >= 1, "bad argument");
     LaunchGeom g = femfct_geom(ctx, levels);

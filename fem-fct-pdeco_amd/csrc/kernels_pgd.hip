@@ -106,6 +106,7 @@ extern "C" {
 
 int femfct_l2_norm_sq_Q(femfct_ctx* ctx, const double* a_dev, const double* b_dev, int32_t num_steps, double dt,
                         double* out_host, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0 && ctx->have_mass, "mass matrix not set");
     ARG_TRY(ctx, a_dev && out_host && num_steps >= 0 && batch >= 1, "bad argument");
     const int levels = num_steps + 1;
@@ -123,6 +124,7 @@ int femfct_l2_norm_sq_Q(femfct_ctx* ctx, const double* a_dev, const double* b_de
 
 int femfct_l2_norm_sq_Omega(femfct_ctx* ctx, const double* a_dev, const double* b_dev, double* out_host,
                             int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0 && ctx->have_mass, "mass matrix not set");
     ARG_TRY(ctx, a_dev && out_host && batch >= 1 && batch <= 65535, "bad argument");
     LaunchGeom g = femfct_geom(ctx, 1);
@@ -138,6 +140,7 @@ int femfct_l2_norm_sq_Omega(femfct_ctx* ctx, const double* a_dev, const double* 
 int femfct_cost_functional(femfct_ctx* ctx, const double* var1, const double* var1_target, const double* control,
                            int32_t control_shared, int32_t num_steps, double dt, double beta, int32_t finaltime,
                            const double* var2, const double* var2_target, double* J_host, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0 && ctx->have_mass, "mass matrix not set");
     ARG_TRY(ctx, var1 && var1_target && control && J_host && num_steps >= 1 && batch >= 1, "bad argument");
     ARG_TRY(ctx, (var2 == nullptr) == (var2_target == nullptr), "var2 and var2_target must be given together");
@@ -171,6 +174,7 @@ int femfct_cost_functional(femfct_ctx* ctx, const double* var1, const double* va
 
 int femfct_descent_pointwise(femfct_ctx* ctx, int64_t count, double beta, const double* c_dev, double scale,
                              const double* x_dev, const double* y_dev, double divisor, double* out_dev) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && c_dev && x_dev && out_dev && count >= 0 && divisor != 0.0, "bad argument");
     int bs = 256;
     int64_t g = (count + bs - 1) / bs;
@@ -183,6 +187,7 @@ int femfct_descent_pointwise(femfct_ctx* ctx, int64_t count, double beta, const 
 
 int femfct_project_control(femfct_ctx* ctx, const double* c_dev, double s, const double* d_dev, double c_lower,
                            double c_upper, double* out_dev, int64_t count) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && c_dev && d_dev && out_dev && count >= 0, "bad argument");
     int bs = 256;
     int64_t g = (count + bs - 1) / bs;

@@ -720,10 +720,19 @@ __device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
     }
 }
 
+// Off-diagonal entries of the mesh's own P1 mass matrix from the cell geometry (right-diagonal mesh): m_ij = cnt_ij |K| / 12
+// with cnt_ij in {0, 1, 2} triangles on the edge -- the bits k_mesh_constants stores (cnt * (area / 12.0) is exact for
+// cnt <= 2), so a limiter that derives them instead of loading six doubles per row computes the identical step.
+// Packed as six 2-bit counts, slots E, NE, N, W, SW, S (the order of k_strip4_cheb_mass).
+__device__ __forceinline__ int mass_edge_counts(int gx, int gy, int nc) {
+    const int c00 = (gx < nc && gy < nc), c10 = (gx > 0 && gy < nc), c01 = (gx < nc && gy > 0), c11 = (gx > 0 && gy > 0);
+    return (c00 + c01) | ((2 * c00) << 2) | ((c00 + c10) << 4) | ((c10 + c11) << 6) | ((2 * c11) << 8) | ((c11 + c01) << 10);
+}
+
 #define FL_H 2
-template <int FL_L>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
+template <int FL_L, int GEOM>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
 __global__ void __launch_bounds__(FL_L * FL_L)
-k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __restrict__ D_,
+k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const double* __restrict__ D_,
                   const double* __restrict__ ulow_, const double* __restrict__ du_, const double* __restrict__ ml,
                   double dt, VecRef out_ref, int64_t out_bstride, EndArgs e) {
     constexpr int W = 7;
@@ -744,11 +753,13 @@ k_tile_flux_limit(int n, int N, const double* __restrict__ M, const double* __re
     const bool have = g.inside && g.kvalid >= 1;
     if (have) {
         double pp = 0.0, pm = 0.0, umax = ui, umin = ui;
+        const int pc = GEOM ? mass_edge_counts(g.gx, g.gy, N - 1) : 0;
+        const double mq = (0.5 * h * h) / 12.0;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             const int64_t idx = (int64_t)s * n + g.i;
             const double uj = su[g.nb[s - 1]];
-            const double mij = M[idx], dij = D_[moff + idx];
+            const double mij = GEOM ? (double)((pc >> (2 * (s - 1))) & 3) * mq : M[idx], dij = D_[moff + idx];
             const double fs = mij * (dui - sd[g.nb[s - 1]]) + dij * (ui - uj);
             f[s - 1] = fs;
             pp += fmax(fs, 0.0);
@@ -787,8 +798,9 @@ namespace {
 // (helpers.py:1818-1870) in one launch: 8 x 8 tile + halo 12 (ten rings for the iterations, two for
 // the limiter: R+- of the ring-1 neighbours).  du never goes to memory.  Same expressions in the same
 // order as k_tile_cheb + k_tile_flux_limit => bitwise the same step.  Latency regime only.
+template <int GEOM>
 __global__ void __launch_bounds__(STRIP_T)
-k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double* __restrict__ b_,
+k_tile_cheb_flux_limit(int n, int N, double h, const double* __restrict__ M, const double* __restrict__ b_,
                        const double* __restrict__ ymid_, const double* __restrict__ yold_, int K, CheOmegas om,
                        double md_scale, const double* __restrict__ D_, const double* __restrict__ ulow_,
                        const double* __restrict__ ml, double dt, VecRef out_ref, int64_t out_bstride, EndArgs e) {
@@ -804,8 +816,15 @@ k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double*
     if (g.inside) {
         md = M[g.i];
         rmd = 1.0 / (md_scale * md);
+        if (GEOM) {
+            const int pc = mass_edge_counts(g.gx, g.gy, N - 1);
+            const double mq = (0.5 * h * h) / 12.0;
 #pragma unroll
-        for (int s = 1; s < W; ++s) mv[s - 1] = M[(int64_t)s * n + g.i];
+            for (int s = 1; s < W; ++s) mv[s - 1] = (double)((pc >> (2 * (s - 1))) & 3) * mq;
+        } else {
+#pragma unroll
+            for (int s = 1; s < W; ++s) mv[s - 1] = M[(int64_t)s * n + g.i];
+        }
         bv = b_[voff + g.i];
         ym = ymid_[voff + g.i];
         yo = yold_[voff + g.i];
@@ -878,6 +897,11 @@ k_tile_cheb_flux_limit(int n, int N, const double* __restrict__ M, const double*
 
 }  // namespace
 
+// the registered mass matrix is the structured mesh's own and may be derived from the cell geometry (FEMFCT_GEOM_MASS)
+bool femfct_geom_mass(const femfct_ctx* ctx) {
+    return ctx->geom_mass && ctx->structured && ctx->mass_is_mesh && ctx->implicit_cols;
+}
+
 // one workgroup per CU is the regime where the fused tail pays (see femfct_tile_plan)
 bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch) {
     if (!ctx->fuse_flux || ctx->N > 512) return false;
@@ -902,8 +926,12 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
     for (int k = k_first; k <= k_last; ++k) om.w[k - k_first] = omegas[k - 1];
     const int t = (ctx->N + 7) / 8;
     femfct_prof_begin(ctx, KC_FLUX);
-    hipLaunchKernelGGL(k_tile_cheb_flux_limit, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b,
-                       in_mid, in_old, K, om, md_scale, D, ulow, ctx->d_ml, dt, out, out_bstride, e);
+    if (femfct_geom_mass(ctx))
+        hipLaunchKernelGGL(k_tile_cheb_flux_limit<1>, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h,
+                           ctx->d_M, b, in_mid, in_old, K, om, md_scale, D, ulow, ctx->d_ml, dt, out, out_bstride, e);
+    else
+        hipLaunchKernelGGL(k_tile_cheb_flux_limit<0>, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h,
+                           ctx->d_M, b, in_mid, in_old, K, om, md_scale, D, ulow, ctx->d_ml, dt, out, out_bstride, e);
     femfct_prof_end(ctx);
     return FEMFCT_OK;
 }
@@ -918,15 +946,17 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
         e.batch = batch; e.ticket = ctx->d_ticket;
     }
     femfct_prof_begin(ctx, KC_FLUX);
+    const bool geom = femfct_geom_mass(ctx);
+#define FL_(PL, G, T_) hipLaunchKernelGGL((k_tile_flux_limit<PL, G>), dim3(T_, T_, batch), dim3(PL * PL), 0, ctx->stream, ctx->n, \
+                                          ctx->N, ctx->h, ctx->d_M, D, ulow, du, ctx->d_ml, dt, out, out_bstride, e)
     if (ctx->N <= 512) {
         const int t = (ctx->N + 11) / 12;
-        hipLaunchKernelGGL(k_tile_flux_limit<16>, dim3(t, t, batch), dim3(256), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
-                           ulow, du, ctx->d_ml, dt, out, out_bstride, e);
+        if (geom) FL_(16, 1, t); else FL_(16, 0, t);
     } else {
         const int t = (ctx->N + 27) / 28;
-        hipLaunchKernelGGL(k_tile_flux_limit<32>, dim3(t, t, batch), dim3(1024), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, D,
-                           ulow, du, ctx->d_ml, dt, out, out_bstride, e);
+        if (geom) FL_(32, 1, t); else FL_(32, 0, t);
     }
+#undef FL_
     femfct_prof_end(ctx);
     return FEMFCT_OK;
 }
@@ -1248,7 +1278,7 @@ k_tile4_jacobi(int n, int N, const double* __restrict__ L_, const double* __rest
     } else {
         bnorm = ctl->bnorm;
         double rmax = BIG ? ctl->rs[(launch - 1) & 1]
-                          : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+                                  : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (wg == 0 && threadIdx.x == 0) {
                 ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
@@ -1422,7 +1452,10 @@ __device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H) {
     ((s) == 0 ? e_[r] : (s) == 1 ? ((r) < 3 ? e_[((r) + 1) & 3] : ea_) : (s) == 2 ? ((r) < 3 ? X[((r) + 1) & 3] : ABOVE) \
      : (s) == 3 ? w_[r] : (s) == 4 ? ((r) > 0 ? w_[((r) + 3) & 3] : wb_) : ((r) > 0 ? X[((r) + 3) & 3] : BELOW))
 
-template <int BIG>
+// MODE 0: residual partials reduced by the next launch's workgroups; 1: more workgroups than in-kernel partials
+// (separate k_reduce_resid); 2: ONE workgroup covers the whole mesh and stops by itself (check_every > 0) -- its own
+// instantiation so that the multi-patch bandwidth kernels carry neither the branch nor its block reduction.
+template <int MODE>
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                 double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
@@ -1446,8 +1479,8 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
         }
     } else {
         bnorm = ctl->bnorm;
-        double rmax = BIG ? ctl->rs[(launch - 1) & 1]
-                          : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        double rmax = (MODE == 1) ? ctl->rs[(launch - 1) & 1]
+                                  : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
         if (rmax <= rel_tol * bnorm) {
             if (wg == 0 && threadIdx.x == 0) {
                 ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
@@ -1502,7 +1535,7 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
         }
         // one workgroup = the whole mesh (check_every > 0): the residual of this sweep's input iterate is known
         // to the workgroup, so it stops by itself -- exact sweep counts, the budget is only an upper bound
-        if (check_every > 0 && (k % check_every) == check_every - 1 && k < K - 1) {
+        if (MODE == 2 && (k % check_every) == check_every - 1 && k < K - 1) {
             double rk = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -1524,7 +1557,7 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
         if (g[r].owned) xout[g[r].i] = x[r];
     rmax = block_reduce(rmax, OpMax(), 0.0, smem);
     if (threadIdx.x == 0) {
-        if (BIG) bigpart[(int64_t)bz * nwg + wg] = rmax;
+        if (MODE == 1) bigpart[(int64_t)bz * nwg + wg] = rmax;
         else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
     }
 }
@@ -1725,9 +1758,12 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
                                ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every);
             hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                                ctx->d_ctl, launch);
+        } else if (check_every > 0) {
+            hipLaunchKernelGGL(k_strip4_jacobi<2>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every);
         } else {
             hipLaunchKernelGGL(k_strip4_jacobi<0>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, 0);
         }
     } else if (big) {
         hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
@@ -1768,7 +1804,7 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
-        if (ctx->t4_dpp && ctx->geom_mass && ctx->structured && ctx->mass_is_mesh && !io_in)
+        if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in)
             hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
                                mid, old, omid, oold, k1 - k0, om, md_scale, H);
         else if (ctx->t4_dpp)

@@ -38,6 +38,7 @@ int femfct_mesh_release(femfct_ctx* ctx) {
 }
 
 extern "C" int femfct_set_mesh_square(femfct_ctx* ctx, double a1, double a2, int32_t n_cells, int32_t order) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx, "null ctx");
     ARG_TRY(ctx, n_cells >= 1 && a2 > a1, "need n_cells >= 1 and a2 > a1");
     ARG_TRY(ctx, order == FEMFCT_ORDER_VERTEX || order == FEMFCT_ORDER_FENICS, "unknown dof order");

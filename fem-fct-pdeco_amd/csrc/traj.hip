@@ -149,6 +149,7 @@ int femfct_solidbody_forward(femfct_ctx* ctx, const double* Arot_ell, const doub
 int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
                                  const double* src_traj, double* u_traj, int32_t num_steps, double dt, double eps,
                                  double rot_scale, double bx, double by, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
     ARG_TRY(ctx, c_traj && u_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
     ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
@@ -198,6 +199,7 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
 int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const double* c_traj, int32_t c_shared,
                              const double* u_traj, const double* uhat, double* p_traj, int32_t num_steps, double dt,
                              double eps, double rot_scale, double bx, double by, int32_t alltime, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set (femfct_set_mesh_square)");
     ARG_TRY(ctx, c_traj && u_traj && uhat && p_traj && num_steps >= 1 && dt > 0 && batch >= 1, "bad argument");
     ARG_TRY(ctx, Arot_ell || rot_scale == 0.0, "Arot_ell is required when rot_scale != 0");
@@ -252,6 +254,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
 
 // per-step solver diagnostics of the most recent trajectory sweep: info[step*batch + b]
 int femfct_traj_info(femfct_ctx* ctx, femfct_step_info* info_host, int32_t num_steps, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && info_host, "null argument");
     ARG_TRY(ctx, num_steps == ctx->log_steps && batch == ctx->log_batch, "no matching trajectory log");
     for (size_t k = 0; k < ctx->h_log.size(); ++k) {

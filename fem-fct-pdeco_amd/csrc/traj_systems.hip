@@ -52,6 +52,7 @@ extern "C" {
 // out = in^T on the registered (structurally symmetric) pattern: assemble_sparse(dot(wind,grad(u))*w*dx)
 // is the transpose of assemble_sparse(dot(wind,grad(w))*u*dx)  (helpers.py:581 vs 681)
 int femfct_ell_transpose(femfct_ctx* ctx, const double* in_ell, double* out_ell) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0 && in_ell && out_ell && in_ell != out_ell, "bad argument");
     LaunchGeom g = femfct_geom(ctx, 1);
     hipLaunchKernelGGL(k_ell_transpose, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->W, ctx->d_cols, ctx->d_tslot,
@@ -63,6 +64,7 @@ int femfct_ell_transpose(femfct_ctx* ctx, const double* in_ell, double* out_ell)
 // Du*Ad - omega1*A  (helpers.py:583)
 int femfct_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a_dev, double beta, const double* b_dev,
                  double* out_dev) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && a_dev && out_dev && count >= 0, "bad argument");
     return femfct_enqueue_axpby(ctx, count, alpha, a_dev, beta, b_dev, out_dev);
 }
@@ -87,6 +89,7 @@ int femfct_set_species_solver(femfct_ctx* ctx, int32_t mode) {
 // Jacobi-preconditioned BiCGStab, x0 = initial guess, synchronises, FEMFCT_ERR_NOT_CONVERGED on failure.
 int femfct_bicgstab(femfct_ctx* ctx, const double* mat_ell, int32_t mat_shared, const double* b_dev,
                     const double* x0_dev, double* x_dev, int32_t batch, femfct_step_info* info_host) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && ctx->n > 0 && mat_ell && b_dev && x0_dev && x_dev && batch >= 1, "bad argument");
     int rc = femfct_ensure_krylov_ws(ctx, batch);
     if (rc != FEMFCT_OK) return rc;
@@ -129,6 +132,7 @@ int femfct_bicgstab(femfct_ctx* ctx, const double* mat_ell, int32_t mat_shared, 
 // freezes for the whole sweep (level 1: helpers.py:950-951) as n doubles per batch member.
 int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c_level, double* u_traj,
                              int32_t num_steps, double dt, double eps, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, Aw_ell && c_level && u_traj, "null argument");
@@ -162,6 +166,7 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
 // helpers.py:968-1038: p(T) = uhat_T - u(T); FCT_alg_ref(-Mat_p, 0, p_{n+1}, non_flux_mat = M_u2(u_n) - M)
 int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double* u_traj, const double* uhat_T,
                              double* p_traj, int32_t num_steps, double dt, double eps, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, Aw_ell && u_traj && uhat_T && p_traj, "null argument");
@@ -195,6 +200,7 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
 int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c_level, double* u_traj,
                           double* v_traj, int32_t num_steps, double dt, const double* par, double rescaling,
                           int32_t batch) {
+    FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, Aw_ell && c_level && u_traj && v_traj && par && rescaling != 0.0, "bad argument");
@@ -250,6 +256,7 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
 int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* u_traj, const double* v_traj,
                           const double* uhat_T, const double* vhat_T, double* p_traj, double* q_traj,
                           int32_t num_steps, double dt, const double* par, int32_t alltime, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, AwT_ell && u_traj && v_traj && uhat_T && vhat_T && p_traj && q_traj && par, "null argument");
@@ -316,6 +323,7 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
 // helpers.py:1250-1385.  par = {delta, Dm, Df, chi, eta}
 int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj, double* v_traj, int32_t num_steps,
                          double dt, const double* par, double rescaling, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, c_level && u_traj && v_traj && par && rescaling != 0.0, "bad argument");
@@ -360,6 +368,7 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
 int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_traj, const double* uhat,
                          const double* vhat, double* p_traj, double* q_traj, const double* c_traj, int32_t num_steps,
                          double dt, const double* par, double rescaling, int32_t alltime, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
     ARG_TRY(ctx, u_traj && v_traj && uhat && vhat && p_traj && q_traj && c_traj && par && rescaling != 0.0, "bad argument");
@@ -411,6 +420,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
 
 // BiCGStab diagnostics of the most recent sweep that used it: info_host[step*batch + b]
 int femfct_traj_krylov_info(femfct_ctx* ctx, femfct_step_info* info_host, int32_t num_steps, int32_t batch) {
+    FEMFCT_ENTER(ctx);
     ARG_TRY(ctx, ctx && info_host, "null argument");
     ARG_TRY(ctx, num_steps == ctx->log_steps && batch == ctx->log_batch &&
                      ctx->h_klog.size() == sizeof(KrylovCtl) * (size_t)num_steps * batch, "no matching Krylov log");

@@ -133,6 +133,13 @@ class Context:
     def set_fusion(self, strips=True, tiles=True):
         check(self.handle, lib.femfct_set_fusion(self.handle, int(bool(strips)), int(bool(tiles))))
 
+    def kernel_regime(self, batch=1) -> int:
+        """_lib.REGIME_*: the Jacobi / Chebyshev kernel family a step with ``batch`` members runs."""
+        return lib.femfct_kernel_regime(self.handle, int(batch))
+
+    def uses_bandwidth_tiles(self, batch=1) -> bool:
+        return self.kernel_regime(batch) == _lib.REGIME_PATCH64
+
     def synchronize(self):
         check(self.handle, lib.femfct_synchronize(self.handle))
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FEMFCT_ABI_VERSION 2   /* 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
+#define FEMFCT_ABI_VERSION 3   /* 3: femfct_kernel_regime; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
 
 typedef struct femfct_ctx femfct_ctx;
 
@@ -87,6 +87,12 @@ int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay o
  * (structured mesh in vertex order); both default on, results agree with the one-sweep kernels to the
  * solver tolerance.  For tests and tuning. */
 int         femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles);
+/* kernel family a step with `batch` members uses on the registered pattern (diagnostic; -1 without a pattern) */
+#define FEMFCT_REGIME_ROWS    0   /* one-sweep row kernels (any ELL pattern) */
+#define FEMFCT_REGIME_STRIPS  1   /* multi-sweep row strips (banded patterns) */
+#define FEMFCT_REGIME_TILE32  2   /* 32 x 32-patch tiles, latency regime (structured mesh, vertex order) */
+#define FEMFCT_REGIME_PATCH64 3   /* 64 x 64-patch register/DPP kernels, bandwidth regime (n * batch >= 90 000) */
+int         femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch);
 
 /* Per-kernel timing with HIP events recorded on the ctx stream around every kernel of the step
  * sequence (used by bench.py for the roofline figures).  While enabled, launches are eager.

@@ -1,0 +1,224 @@
+"""North-star parity gate AT THE BASELINE SIZES (-m gpu): BASELINE.json asks for "solution L2 error < 1e-6 vs
+reference on the same (dx, dt) grid".  Every case below runs the HIP path through the C ABI on the grid and
+step count its config names and compares whole trajectories with the CPU oracle (pinned against the real
+reference by tests/test_oracle_golden.py):
+
+  C2   advection_solidbody_FCT_PDECO_finaltime.py:38-60,175-221   [-1,1]^2 81x81, dt 1e-3, 250 + 250 steps
+  C3   Schnak_FCT_PDECO_refactored.py:44-62, helpers.py:511-698    UnitSquare 41x41, dt 5e-4, 200 + 200 steps
+  C4   chemotaxis_FCT_PDECO_AT_refactored.py:46-75, helpers.py:1250-1581   same grid, all-time adjoint
+  +    331x331 nodes, 2 steps: the size class that selects the 64-patch bandwidth kernels (k_strip4_*)
+
+Tolerance: relative l2 error per trajectory < 1e-6 (north star); the measured errors are printed and are
+expected around 1e-11.  Mass and bounds are checked where the scheme guarantees them.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6            # BASELINE.json north_star
+EXPECT = 1e-8         # what the solver tolerances (1e-13 per solve) should leave after 250 steps
+
+
+@pytest.fixture(scope="module")
+def hp():
+    mod = importlib.import_module("fem-fct-pdeco_amd")
+    mod.fct_helpers.VERBOSE = False
+    return mod
+
+
+@pytest.fixture(scope="module")
+def solvers():
+    return importlib.import_module("fem-fct-pdeco_amd.solvers")
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _oracle(a1, a2, nc):
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    mesh = SquareMesh(a1, a2, nc)
+    return mesh, P1Assembler(mesh)
+
+
+def _slotted_disc(a1, a2, deltax, slit=0.05):
+    """advection_solidbody_FCT_PDECO_finaltime.py:71-88 (np.arange grid, vertex order)."""
+    X = np.arange(a1, a2 + deltax, deltax)
+    X, Y = np.meshgrid(X, X)
+    R = np.sqrt(X ** 2 + (Y - 1 / 3) ** 2)
+    return ((R < 1 / 3) & ((np.abs(X) > slit) | (Y > 0.5))).astype(np.float64).reshape(-1)
+
+
+def _report(name, **errs):
+    print(f"[fullsize] {name}: " + ", ".join(f"{k}={v:.3e}" for k, v in errs.items()))
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_c2_solidbody_81x81_250_steps_forward_adjoint(hp, solvers, order):
+    """BASELINE configs[1] at its own size, both device orderings (FEniCS DoF order = the drop-in layout,
+    vertex order = the layout bench.py times)."""
+    from oracle import traj as otraj
+    from oracle.assembly import row_lump_diag
+    from helpers_golden import load
+    a1, a2, deltax, dt, Nt, om = -1.0, 1.0, 0.1 / 2 / 2, 1e-3, 250, np.pi / 40
+    nc = round((a2 - a1) / deltax)
+    omesh, asm = _oracle(a1, a2, nc)
+    n = omesh.nodes
+    assert n == 6561
+    v2d = omesh.vertex_to_dof
+    u0 = np.zeros(n)
+    u0[v2d] = _slotted_disc(a1, a2, deltax)
+    assert int(u0.sum()) == 486
+    t = np.linspace(0.0, 1.0, Nt + 1)[:, None]
+    ck = np.zeros((Nt + 1, n))
+    ck[:, v2d] = np.clip(1.5 + np.sin(2 * np.pi * (omesh.x[None, :] + t)) * np.cos(np.pi * omesh.y[None, :]) + 0.5 * t, 0, 5)
+    ck = ck.reshape(-1)
+    uhat = load("solidbody_t0.25_u.npz")["u"]            # the reference's own target (data/solidbody_t0.25_u.csv)
+    sb = otraj.SolidBody(asm, om=om)
+    uk_o = np.zeros((Nt + 1) * n)
+    uk_o[:n] = u0
+    otraj.solidbody_forward(sb, ck, uk_o, n, Nt, dt)
+    pk_o = otraj.solidbody_adjoint(sb, ck, uk_o, uhat, np.zeros_like(uk_o), n, Nt, dt, optim="finaltime")
+
+    def to_dev(x):
+        return x if order == 1 else x.reshape(-1, n)[:, v2d].reshape(-1)
+
+    def from_dev(x):
+        if order == 1:
+            return x
+        out = np.empty_like(x.reshape(-1, n))
+        out[:, v2d] = x.reshape(-1, n)
+        return out.reshape(-1)
+
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(a1, a2, nc), Nt, dt, om=om, order=order)
+    try:
+        uk = np.zeros((Nt + 1) * n)
+        uk[:n] = to_dev(u0)
+        prob.solve_state(to_dev(ck), uk)
+        assert not np.any(prob.solver_log(1)["flags"] & hp.FLAG_SOLVER_BUDGET)
+        pk = prob.solve_adjoint(to_dev(ck), uk, to_dev(uhat), np.zeros_like(uk), optim="finaltime")
+        assert not np.any(prob.solver_log(1)["flags"] & hp.FLAG_SOLVER_BUDGET)
+        eu, ep = rel(from_dev(uk), uk_o), rel(from_dev(pk), pk_o)
+        eT = rel(from_dev(uk)[Nt * n:], uk_o[Nt * n:])
+        _report(f"C2 order={order}", u_rel_l2=eu, u_T_rel_l2=eT, p_rel_l2=ep)
+        assert eu < TOL and ep < TOL and eT < TOL
+        assert eu < EXPECT and ep < EXPECT
+        # pure rotation (c = 0): divergence-free wind, 1^T A = 0 => the lumped mass is conserved and the
+        # slotted disc stays in [0, 1] (it never reaches the boundary)
+        uk2 = np.zeros((Nt + 1) * n)
+        uk2[:n] = to_dev(u0)
+        prob.solve_state(np.zeros((Nt + 1) * n), uk2)
+        ml = to_dev(row_lump_diag(asm.mass()))
+        mass = uk2.reshape(Nt + 1, n) @ ml
+        assert np.abs(np.diff(mass)).max() <= 1e-12 * mass[0]
+        assert uk2.min() >= -1e-14 and uk2.max() <= 1 + 1e-14
+    finally:
+        prob.close()
+
+
+def test_c3_schnakenberg_41x41_200_steps_forward_adjoint(hp):
+    """Schnakenberg system at dx = 0.025, dt = 5e-4, T = 0.1: final-time adjoint (HEAD driver,
+    Schnak_FCT_PDECO_refactored.py) and the all-time misfit of the config-3 script."""
+    from oracle import traj as otraj
+    mesh, asm = _oracle(0.0, 1.0, 40)
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 200, 5e-4
+    assert n == 1681
+    rng = np.random.default_rng(31)
+    u0, v0 = hp.schnak_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+    ctrl = 0.1 + 0.05 * rng.random((Nt + 1) * n)
+    uo = np.zeros((Nt + 1) * n); vo = np.zeros((Nt + 1) * n)
+    uo[:n], vo[:n] = u0, v0
+    ug, vg = uo.copy(), vo.copy()
+    otraj.solve_schnak_system(ctrl, uo, vo, asm, n, Nt, dt)
+    hp.solve_schnak_system(ctrl, ug, vg, V, n, Nt, dt, None)
+    eu, ev = rel(ug, uo), rel(vg, vo)
+    uhat, vhat = 0.9 * uo[Nt * n:], 1.1 * vo[Nt * n:]
+    z = lambda: np.zeros_like(uo)
+    po, qo = otraj.solve_adjoint_schnak_system(uo, vo, uhat, vhat, z(), z(), Nt * dt, asm, n, Nt, dt)
+    pg, qg = hp.solve_adjoint_schnak_system(ug, vg, uhat, vhat, z(), z(), Nt * dt, V, n, Nt, dt, None)
+    ep, eq = rel(pg, po), rel(qg, qo)
+    uh, vh = 0.9 * uo + 0.01, 1.1 * vo
+    po, qo = otraj.solve_adjoint_schnak_system(uo, vo, uh, vh, z(), z(), Nt * dt, asm, n, Nt, dt, None, "alltime")
+    pg, qg = hp.solve_adjoint_schnak_system(ug, vg, uh, vh, z(), z(), Nt * dt, V, n, Nt, dt, None, optim="alltime")
+    epa, eqa = rel(pg, po), rel(qg, qo)
+    _report("C3 Schnakenberg", u=eu, v=ev, p_ft=ep, q_ft=eq, p_at=epa, q_at=eqa)
+    for e in (eu, ev, ep, eq, epa, eqa):
+        assert e < TOL
+    assert max(eu, ev) < EXPECT
+    assert ug.min() > 0 and vg.min() > 0                       # concentrations stay positive
+
+
+def test_c4_chemotaxis_41x41_200_steps_forward_adjoint(hp):
+    """Chemotaxis system (chemotaxis_FCT_PDECO_AT_refactored.py:46-75): seeded IC of helpers.py:1242-1243,
+    dt = 5e-4, T = 0.1, rescaling 1/10, all-time adjoint with the control refreshed per step."""
+    from oracle import traj as otraj
+    mesh, asm = _oracle(0.0, 1.0, 40)
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 200, 5e-4
+    rng = np.random.default_rng(41)
+    u0, v0 = hp.chtxs_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+    ctrl = 20 * rng.random((Nt + 1) * n)
+    uo = np.zeros((Nt + 1) * n); vo = np.zeros((Nt + 1) * n)
+    uo[:n], vo[:n] = u0, v0
+    ug, vg = uo.copy(), vo.copy()
+    otraj.solve_chtxs_system(ctrl, uo, vo, asm, n, Nt, dt)
+    hp.solve_chtxs_system(ctrl, ug, vg, V, n, Nt, dt, None)
+    eu, ev = rel(ug, uo), rel(vg, vo)
+    uhat, vhat = 0.9 * uo + 0.01 * rng.random(uo.size), 1.05 * vo
+    z = lambda: np.zeros_like(uo)
+    po, qo = otraj.solve_adjoint_chtxs_system(uo, vo, uhat, vhat, z(), z(), ctrl, Nt * dt, asm, n, Nt, dt, None, "alltime")
+    pg, qg = hp.solve_adjoint_chtxs_system(ug, vg, uhat, vhat, z(), z(), ctrl, Nt * dt, V, n, Nt, dt, None, "alltime")
+    ep, eq = rel(pg, po), rel(qg, qo)
+    _report("C4 chemotaxis", u=eu, v=ev, p=ep, q=eq)
+    for e in (eu, ev, ep, eq):
+        assert e < TOL
+    assert max(eu, ev) < EXPECT
+    assert ug.min() > 0 and vg.min() > 0
+
+
+@pytest.mark.parametrize("nc", [330, 511])
+def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
+    """n >= 90 000 selects the 64 x 64-patch kernels (k_strip4_jacobi / k_strip4_cheb[_mass] and the fused
+    limiter); here they face the CPU oracle directly (not only the one-sweep GPU kernels): 2 forward + 2 adjoint
+    steps at 331^2 (partial edge patches) and 512^2 nodes."""
+    from oracle import traj as otraj
+    Nt = 2
+    omesh, asm = _oracle(-1.0, 1.0, nc)
+    n = omesh.nodes
+    dt = 1e-3 * (2.0 / nc) / 0.025                      # the CFL number of C2
+    rng = np.random.default_rng(13)
+    x, y = omesh.x, omesh.y                             # vertex order
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1)
+    v2d = omesh.vertex_to_dof
+
+    def to_dof(a):
+        out = np.empty_like(a.reshape(-1, n))
+        out[:, v2d] = a.reshape(-1, n)
+        return out.reshape(-1)
+
+    sb = otraj.SolidBody(asm, om=np.pi / 40)
+    uk_o = np.zeros((Nt + 1) * n)
+    uk_o[:n] = to_dof(u0)
+    otraj.solidbody_forward(sb, to_dof(c), uk_o, n, Nt, dt)
+    uhat_o = 0.9 * uk_o[Nt * n:] + 0.01
+    pk_o = otraj.solidbody_adjoint(sb, to_dof(c), uk_o, uhat_o, np.zeros_like(uk_o), n, Nt, dt, optim="finaltime")
+
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1.0, 1.0, nc), Nt, dt, order=hp.ORDER_VERTEX)
+    try:
+        assert prob.ctx.uses_bandwidth_tiles(1), "this size must select the 64-patch kernels"
+        uk = np.zeros((Nt + 1) * n)
+        uk[:n] = u0
+        prob.solve_state(c, uk)
+        assert not np.any(prob.solver_log(1)["flags"] & hp.FLAG_SOLVER_BUDGET)
+        pk = prob.solve_adjoint(c, uk, uhat_o.reshape(-1, n)[:, v2d].reshape(-1), np.zeros_like(uk), optim="finaltime")
+        eu, ep = rel(to_dof(uk), uk_o), rel(to_dof(pk), pk_o)
+        _report(f"bandwidth kernels {nc + 1}^2", u_rel_l2=eu, p_rel_l2=ep)
+        assert eu < 1e-9 and ep < 1e-9
+    finally:
+        prob.close()

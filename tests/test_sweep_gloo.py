@@ -76,3 +76,37 @@ def test_sweep_single_process_and_shard():
     assert sweep.shard(list(range(8)), 3, 8) == [3]
     assert sweep.shard(list(range(5)), 1, 2) == [1, 3]
     assert sweep.sweep([], lambda b: b) == []
+
+
+def test_bench_multi_rank_control_flow_under_gloo():
+    """bench.py --gpus 2 with WORLD_SIZE unset: the script must start its own ranks (a child
+    torch.distributed.run, nothing exec'd), rendezvous on 127.0.0.1, all-gather the per-rank cost, take the
+    max-over-ranks time and print ONE JSON line from rank 0.  --stub-solver swaps the GPU problem for a stub and
+    RCCL for gloo; every other line of the N > 1 path is the one the 8-GPU run executes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--stub-solver"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["stub"] is True
+    # rank r's stub cost is 100 + r + beta_r with the C5 betas 10^(-r/2): both ranks' values reached rank 0
+    assert r["costs_all_ranks"] == [100.0 + 0 + 1.0, 100.0 + 1 + 10.0 ** -0.5]
+    # max over ranks: rank 1 sleeps 20 ms per step
+    assert r["ms_per_step"] >= 20.0
+    assert abs(r["value"] - 2 * 250 * 2 * 3 / (r["ms_per_step"] * 3 / 1e3)) < 1e-6 * r["value"]
+
+
+def test_bench_refuses_mismatched_world_size():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-solver"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

@@ -59,9 +59,15 @@ def main():
         wr = csv.DictWriter(f, fieldnames=list(rows[0]))
         wr.writeheader()
         wr.writerows(rows)
+    # stamped with the identity of the kernel sources the measured library was built from: bench.py echoes these
+    # bytes as roofline.traffic only when its own build carries the same stamp
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_sha16
     tj = os.path.join(os.path.dirname(prefix), "traffic.json")
     data = json.load(open(tj)) if os.path.exists(tj) else {}
-    data[f"n{n}"] = traffic
+    data = {k: v for k, v in data.items() if isinstance(v, dict) and "bytes_per_launch" in v}   # drop unstamped records
+    data[f"n{n}"] = {"source_sha16": source_sha16(), "bytes_per_launch": traffic,
+                     "method": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate rocprofv3 --pmc passes"}
     json.dump(data, open(tj, "w"), indent=1, sort_keys=True)
     for r in rows:
         print(f"{r['kernel']:22s} launches {r['launches']:4d}  HBM {r['hbm_bytes_per_row']:7.1f} B/row/launch")

@@ -1,14 +1,34 @@
+#!/bin/bash
+# One pass on ONE MI355X box that regenerates everything under profiles/ from the library as built from the
+# current sources, so that kernel stats, PMC traffic and the bench line describe the same binary:
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
+# Outputs land in gpurun_out/prof/ (merged back by gpurun); copy them into profiles/ with
+#   cp gpurun_out/prof/r02_* gpurun_out/prof/traffic.json profiles/
+# Order: PMC passes first (traffic.json, stamped with source_sha16), then the plain bench run (whose
+# roofline.traffic echoes that stamp-checked file), then the kernel trace.
 set -e
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof
-timeout -k 10 400 python bench.py > gpurun_out/prof/bench.json 2> gpurun_out/prof/bench.err
+TAG=${1:-r02}
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/prof
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/kt -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --batched "" > $GRAFT_REPO_ROOT/gpurun_out/prof/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof/kt.err
-timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/pf -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --pgd-iters 0 --batched "" --steps 1 --warmup 1 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/prof/pf.err
-timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/pw -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --pgd-iters 0 --batched "" --steps 1 --warmup 1 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/prof/pw.err
-cd $GRAFT_REPO_ROOT/gpurun_out/prof
-cp $(find kt -name "*kernel_stats.csv" | head -1) kernel_stats.csv
-cp $(find pf -name "*counter_collection.csv" | head -1) fetch.csv
-cp $(find pw -name "*counter_collection.csv" | head -1) write.csv
-rm -rf kt pf pw
-ls -la
+N_ROOF=4198401          # 2049^2, the roofline mesh of bench.py
+PMC_ARGS="--cpu-sample 0 --pgd-iters 0 --batched= --steps 1 --warmup 1"
+echo "[refresh] PMC FETCH_SIZE pass"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pf.err
+echo "[refresh] PMC WRITE_SIZE pass"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pw -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pw.err
+cp $(find $OUT/pf -name "*counter_collection.csv" | head -1) $OUT/fetch.csv
+cp $(find $OUT/pw -name "*counter_collection.csv" | head -1) $OUT/write.csv
+cp $REPO/profiles/traffic.json $OUT/traffic.json 2>/dev/null || true
+python3 $REPO/tools/pmc_traffic.py $OUT/fetch.csv $OUT/write.csv $N_ROOF $OUT/${TAG} > $OUT/${TAG}_pmc_summary.txt
+cp $OUT/traffic.json $REPO/profiles/traffic.json      # on the box: the bench run below reads it
+echo "[refresh] bench run"
+cd $REPO
+timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+echo "[refresh] kernel trace"
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --cpu-sample 0 --batched= > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+rm -rf $OUT/kt $OUT/pf $OUT/pw $OUT/fetch.csv $OUT/write.csv
+ls -la $OUT
