@@ -150,7 +150,8 @@ def test_c3_schnakenberg_41x41_200_steps_forward_adjoint(hp):
     for e in (eu, ev, ep, eq, epa, eqa):
         assert e < TOL
     assert max(eu, ev) < EXPECT
-    assert ug.min() > 0 and vg.min() > 0                       # concentrations stay positive
+    # same extrema as the reference path (the reacting u-species does leave [0, inf) on this coarse grid: so does the oracle)
+    assert abs(ug.min() - uo.min()) < 1e-9 and abs(ug.max() - uo.max()) < 1e-9 and abs(vg.min() - vo.min()) < 1e-9
 
 
 def test_c4_chemotaxis_41x41_200_steps_forward_adjoint(hp):
@@ -178,7 +179,7 @@ def test_c4_chemotaxis_41x41_200_steps_forward_adjoint(hp):
     for e in (eu, ev, ep, eq):
         assert e < TOL
     assert max(eu, ev) < EXPECT
-    assert ug.min() > 0 and vg.min() > 0
+    assert abs(ug.min() - uo.min()) < 1e-9 and abs(ug.max() - uo.max()) < 1e-9 and abs(vg.min() - vo.min()) < 1e-9
 
 
 @pytest.mark.parametrize("nc", [330, 511])
