@@ -71,6 +71,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     dev_free(&ctx->d_du); dev_free(&ctx->d_y0); dev_free(&ctx->d_y1); dev_free(&ctx->d_y2); dev_free(&ctx->d_rdu);
     dev_free(&ctx->d_rp); dev_free(&ctx->d_rm); dev_free(&ctx->d_part); dev_free(&ctx->d_ctl);
     dev_free(&ctx->d_bigpart); ctx->bigpart_count = 0;
+    dev_free(&ctx->d_Lmask);
     dev_free(&ctx->d_partk);
     dev_free(&ctx->d_hA); dev_free(&ctx->d_hN); dev_free(&ctx->d_hrhs); dev_free(&ctx->d_hu);
     dev_free(&ctx->d_hout); dev_free(&ctx->d_hcsr);
@@ -128,6 +129,8 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     A_(d_part, (size_t)batch * 4 * FEMFCT_MAX_PARTIALS);
     A_(d_ctl, (size_t)batch);
     A_(d_partk, (size_t)batch * 16 * FEMFCT_MAX_PARTIALS);
+    A_(d_Lmask, (size_t)batch * 6 * (((size_t)ctx->n + 63) / 64) + 1);   // word 0 stays zero (read in place of vanishing entries); masks from word 1
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_Lmask, 0, 8, ctx->stream));
     {
         TilePlan tp;
         ctx->bigpart_count = 0;
@@ -226,6 +229,14 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_DUDT")) ctx->fuse_dudt = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
+    if (const char* e = getenv("FEMFCT_LMASK")) ctx->l_mask = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_INLINE_OPS")) ctx->inline_ops = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_T4_STAGGER_US")) {
+        const double us = atof(e);
+        int pat = 7;
+        if (const char* p = getenv("FEMFCT_T4_STAGGER_PAT")) pat = atoi(p);
+        ctx->t4_stagger = us > 0 ? ((int)(us * 100.0) & 0xffffff) | ((pat & 15) << 24) : 0;
+    }
     if (const char* e = getenv("FEMFCT_SINGLE_PATCH_BATCH")) { int v = atoi(e); ctx->single_patch_min_batch = v > 0 ? v : (1 << 30); }
     if (const char* e = getenv("FEMFCT_MESH_SOLVE")) ctx->mesh_solve = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_GEOM_MASS")) ctx->geom_mass = atoi(e) != 0;

@@ -75,6 +75,8 @@ struct femfct_ctx {
     bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
+    int t4_stagger = 600 | (7 << 24);   // 64-patch Jacobi launches of >= 4 rounds: first-round stagger, ticks of 10 ns | pattern << 24
+                                        // (FEMFCT_T4_STAGGER_US / _PAT; 6 us, second half of every XCD; 0 = off)
     int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always
     bool fuse_end = true;       // log + level advance done by the last workgroup of the step's final kernel
     bool fuse_build = true;     // low-order operator construction inside the first tile-Jacobi launch (small grids)
@@ -97,6 +99,9 @@ struct femfct_ctx {
     StepCtl* d_ctl = nullptr;                                         // [B]
     double* d_partk = nullptr;       // [B][16][MAX_PARTIALS] per-sweep residual partials of the last fused launch
     double* d_bigpart = nullptr;     // [B * bigpart_count] residual partials of fused launches on large grids
+    unsigned long long* d_Lmask = nullptr;   // [B][6][ceil(n/64)] bit i of slot s: l_(i,s) != 0 (written by k_build_low for the 64-patch Jacobi kernels)
+    bool inline_ops = true;          // solid-body sweeps in the bandwidth regime derive A inside the step kernels (FEMFCT_INLINE_OPS)
+    bool l_mask = true;              // skip the exactly-zero off-diagonals of L when loading Jacobi patches (FEMFCT_LMASK)
     int64_t bigpart_count = 0;
     // host staging for the *_host convenience calls
     double *d_hA = nullptr, *d_hN = nullptr, *d_hrhs = nullptr, *d_hu = nullptr, *d_hout = nullptr, *d_hcsr = nullptr;
@@ -231,7 +236,8 @@ bool femfct_single_patch(const femfct_ctx* ctx, int32_t batch);
 // launches and sweeps per launch the low-order solve of femfct_enqueue_step_mat will use for a budget
 bool femfct_jacobi_plan(const femfct_ctx* ctx, int budget, int batch, int* K, int* launches);
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch, int H = 8, int K = 8, int check_every = 0);
+                                int g_build, int32_t batch, int H = 8, int K = 8, int check_every = 0,
+                                const unsigned long long* lmask = nullptr);
 int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
                               double* bufB0, double* bufB1, int32_t batch,

@@ -5,26 +5,9 @@
 #include "femfct_internal.h"
 #include "device_utils.h"
 #include "stencil.h"
+#include "solidbody_op.h"
 
 namespace {
-
-struct NodeXY { int ix, iy; };
-
-__device__ __forceinline__ NodeXY node_xy(int i, const int32_t* __restrict__ d2v, int N) {
-    int v = d2v ? d2v[i] : i;
-    return NodeXY{v % N, v / N};
-}
-
-template <class F>
-__device__ __forceinline__ void for_each_tri(NodeXY p, int nc, F&& f) {
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        const TriInfo T = tri_info(t);
-        int cx = p.ix + T.cdx, cy = p.iy + T.cdy;
-        if (cx < 0 || cy < 0 || cx >= nc || cy >= nc) continue;
-        f(T, cx, cy);
-    }
-}
 
 // ---------------------------------------------------------------------------
 // M = u*v*dx, Ad = dot(grad(u),grad(v))*dx, ml = row_lump(M)   (helpers.py:553-555)
@@ -122,30 +105,14 @@ __global__ void k_ops_solidbody(int n, int N, int nc, double h, const int32_t* _
                       bz * c_bstride;
     double* A = A_ + (int64_t)blockIdx.y * STENCIL_W * n;
     RowRange rr = block_rows(n);
-    const double m12 = 0.5 * h * h / 12.0;
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
         NodeXY p = node_xy(i, d2v, N);
         double cv[STENCIL_W];
         cv[0] = c[i];
 #pragma unroll
         for (int s = 1; s < STENCIL_W; ++s) cv[s] = c[cols[(int64_t)s * n + i]];
-        double acc[STENCIL_W] = {0, 0, 0, 0, 0, 0, 0};
-        for_each_tri(p, nc, [&](const TriInfo& T, int, int) {
-            double c0 = cv[T.slot[0]], c1 = cv[T.slot[1]], c2 = cv[T.slot[2]];
-            // b . grad c_h  (constant on the triangle)
-            double gcx = (c0 * tri_gx(T.type, 0) + c1 * tri_gx(T.type, 1) + c2 * tri_gx(T.type, 2)) / h;
-            double gcy = (c0 * tri_gy(T.type, 0) + c1 * tri_gy(T.type, 1) + c2 * tri_gy(T.type, 2)) / h;
-            double bgc = bx * gcx + by * gcy;
-            double bgp = (bx * tri_gx(T.type, T.pl) + by * tri_gy(T.type, T.pl)) / h;
-            double csum = c0 + c1 + c2;
-            double ck[3] = {c0, c1, c2};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                double d1 = bgc * m12 * (k == T.pl ? 2.0 : 1.0);
-                double d2 = bgp * m12 * (ck[k] + csum);
-                acc[T.slot[k]] += d1 + d2;
-            }
-        });
+        double acc[STENCIL_W], accT[STENCIL_W];
+        sb_drift_row<false>(p, nc, h, cv, bx, by, acc, accT);
 #pragma unroll
         for (int k = 0; k < STENCIL_W; ++k) {
             int64_t idx = (int64_t)k * n + i;

@@ -22,6 +22,7 @@
 #include "device_utils.h"
 #include "solve_ctl.h"
 #include "forms.h"
+#include "solidbody_op.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -60,22 +61,60 @@ __device__ __forceinline__ int tslot_of(const uint8_t* __restrict__ tslot, int n
     return tslot[(int64_t)s * n + i];
 }
 
+// Where a step kernel gets the entries of the flux matrix A from.  MatOp: a stored ELL matrix (any caller).
+// SbOp: the drift-control operator derived on the fly from Arot and the control's 1-ring (bandwidth regime of the
+// solid-body sweeps: saves writing A once and reading it twice per step; solidbody_op.h keeps the bits identical).
+struct MatOp {
+    const double* A;
+    int n;
+    __device__ __forceinline__ void row(int, unsigned) {}
+    __device__ __forceinline__ double a(int s, int i) const { return A[(int64_t)s * n + i]; }
+    __device__ __forceinline__ double at(int, int, int j, int ts) const { return A[(int64_t)ts * n + j]; }
+};
+
+template <bool WITH_T>
+struct SbOp {
+    SbOpArgs p;
+    const double* c;
+    int n, Nw;
+    double h;
+    double acc[STENCIL_W], accT[STENCIL_W];
+    __device__ __forceinline__ void row(int i, unsigned mask) {
+        double cv[STENCIL_W];
+        cv[0] = c[i];
+#pragma unroll
+        for (int s = 1; s < STENCIL_W; ++s) cv[s] = c[col_of<1>(nullptr, n, Nw, mask, s, i)];
+        const int iy = i / Nw;
+        sb_drift_row<WITH_T>(NodeXY{i - iy * Nw, iy}, Nw - 1, h, cv, p.bx, p.by, acc, accT);
+    }
+    __device__ __forceinline__ double a(int s, int i) const {
+        const int64_t idx = (int64_t)s * n + i;
+        return p.eps * (p.eps != 0.0 ? p.Ad[idx] : 0.0) + p.sigma * (p.rot_scale * p.Arot[idx] + acc[s]);
+    }
+    // a_ji for the neighbour j in slot s (its slot towards i is ts); Ad is symmetric to the bit
+    __device__ __forceinline__ double at(int s, int i, int j, int ts) const {
+        return p.eps * (p.eps != 0.0 ? p.Ad[(int64_t)s * n + i] : 0.0) +
+               p.sigma * (p.rot_scale * p.Arot[(int64_t)ts * n + j] + accT[s]);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // k_build_low: artificial diffusion + low-order operator + rhs (helpers.py:1769-1780)
 // ---------------------------------------------------------------------------
-template <int WT, int BS, int IMP>
-__global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const int32_t* __restrict__ cols,
-                            const uint8_t* __restrict__ tslot, MatRef A_ref,
+template <int WT, int BS, int IMP, class AOp>
+__device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int32_t* __restrict__ cols,
+                            const uint8_t* __restrict__ tslot, AOp op,
                             const double* __restrict__ N_, int nshared, VecRef rhs_ref, VecRef u_ref,
                             int64_t rhs_bstride, int64_t u_bstride,
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
-                            double* __restrict__ part, StepCtl* __restrict__ ctl_) {
+                            double* __restrict__ part, StepCtl* __restrict__ ctl_,
+                            unsigned long long* __restrict__ lmask) {
     __shared__ double smem[32];
     const int W = WT ? WT : Wrt;
     const int bz = blockIdx.y;
+    const int64_t nwords = ((int64_t)n + 63) >> 6;
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
-    const double* A = mat_ptr(A_ref, bz);
     const double* Nm = N_ ? N_ + (nshared ? 0 : moff) : nullptr;
     const double* rhs = vec_ptr(rhs_ref);
     if (rhs) rhs += bz * rhs_bstride;
@@ -95,14 +134,15 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
     double bmax = 0.0, rsmin = INFINITY;
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
         const unsigned mask = nb_mask<IMP>(i, Nw);
+        op.row(i, mask);
         double dsum = 0.0, rs = 0.0;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
             int j = col_of<IMP>(cols, n, Nw, mask, s, i);
             int ts = tslot_of<IMP>(tslot, n, mask, s, i);
-            double a = A[idx];
-            double at = A[(int64_t)ts * n + j];
+            double a = op.a(s, i);
+            double at = op.at(s, i, j, ts);
             double d = (j != i) ? fmax(0.0, fmax(a, at)) : 0.0;   // d_ij = max(0, a_ij, a_ji)
             dsum += d;
             double l = dt * (a - d);
@@ -110,9 +150,15 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
             L[idx] = l;
             D[idx] = d;
             rs += l;
+            // which entries of this slot are exactly zero (the low-order operator is an upwind stencil: about half
+            // of its off-diagonals vanish): one bit per row, one 64-bit word per wave (row chunks are 64-aligned)
+            if (lmask) {
+                const unsigned long long nzb = __ballot(l != 0.0);
+                if ((threadIdx.x & 63) == 0) lmask[((int64_t)bz * nwords + (i >> 6)) * (W - 1) + (s - 1)] = nzb;   // [word][slot]
+            }
         }
         double mli = ml[i];
-        double ld = mli + dt * (A[i] + dsum);                      // d_ii = -sum_j d_ij
+        double ld = mli + dt * (op.a(0, i) + dsum);                // d_ii = -sum_j d_ij
         if (Nm) ld += dt * Nm[i];
         L[i] = ld;
         D[i] = -dsum;
@@ -131,6 +177,33 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
         p[2 * FEMFCT_MAX_PARTIALS + blockIdx.x] = bmax;
         p[3 * FEMFCT_MAX_PARTIALS + blockIdx.x] = rsmin;
     }
+}
+
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const int32_t* __restrict__ cols,
+                            const uint8_t* __restrict__ tslot, MatRef A_ref,
+                            const double* __restrict__ N_, int nshared, VecRef rhs_ref, VecRef u_ref,
+                            int64_t rhs_bstride, int64_t u_bstride,
+                            const double* __restrict__ ml, double dt, double* __restrict__ L_,
+                            double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
+                            double* __restrict__ part, StepCtl* __restrict__ ctl_,
+                            unsigned long long* __restrict__ lmask) {
+    build_low_body<WT, BS, IMP>(n, Wrt, Nw, cols, tslot, MatOp{mat_ptr(A_ref, blockIdx.y), n}, N_, nshared, rhs_ref, u_ref,
+                                rhs_bstride, u_bstride, ml, dt, L_, D_, b_, x0_, part, ctl_, lmask);
+}
+
+// the same with the solid-body operator derived on the fly (structured mesh, vertex order)
+template <int BS>
+__global__ void __launch_bounds__(BS) k_build_low_sb(int n, int Nw, double h, SbOpArgs sb, VecRef rhs_ref, VecRef u_ref,
+                            int64_t rhs_bstride, int64_t u_bstride,
+                            const double* __restrict__ ml, double dt, double* __restrict__ L_,
+                            double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
+                            double* __restrict__ part, StepCtl* __restrict__ ctl_,
+                            unsigned long long* __restrict__ lmask) {
+    SbOp<true> op;
+    op.p = sb; op.c = vec_ptr(sb.c) + blockIdx.y * sb.c_bstride; op.n = n; op.Nw = Nw; op.h = h;
+    build_low_body<7, BS, 1>(n, 7, Nw, nullptr, nullptr, op, nullptr, 0, rhs_ref, u_ref, rhs_bstride, u_bstride, ml, dt,
+                             L_, D_, b_, x0_, part, ctl_, lmask);
 }
 
 // ---------------------------------------------------------------------------
@@ -200,8 +273,8 @@ __global__ void __launch_bounds__(BS) k_jacobi(int n, int Wrt, int Nw, const int
 // k_dudt_rhs: r = rhs - A u_L (helpers.py:1814) fused with Chebyshev iterate 1
 // (y_1 = omega_1 * r / (1.25 diag M), helpers.py:175-182 with y_0 = y_-1 = 0).
 // ---------------------------------------------------------------------------
-template <int WT, int BS, int IMP>
-__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, MatRef A_ref,
+template <int WT, int BS, int IMP, class AOp>
+__device__ __forceinline__ void dudt_rhs_body(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, AOp op,
                            VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
                            const double* __restrict__ xa_, const double* __restrict__ xb_,
                            double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
@@ -217,8 +290,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
     const int parity = ctl->done ? ctl->parity : (budget & 1);
     finalize_solve(ctl, p, part_count ? part_count : (int)gridDim.x, budget, iters_per_unit, rel_tol, smem,
                    partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, blockIdx.x == 0);
-    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
-    const double* A = mat_ptr(A_ref, bz);
+    const int64_t voff = (int64_t)bz * n;
     const double* x = (parity ? xb_ : xa_) + voff;
     const double* rhs = vec_ptr(rhs_ref);
     if (rhs) rhs += bz * rhs_bstride;
@@ -228,18 +300,43 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
     RowRange rr = block_rows(n);
     for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
         const unsigned mask = nb_mask<IMP>(i, Nw);
+        op.row(i, mask);
         double xi = x[i];
-        double acc = A[i] * xi;
+        double acc = op.a(0, i) * xi;
 #pragma unroll
-        for (int s = 1; s < W; ++s) {
-            int64_t idx = (int64_t)s * n + i;
-            acc = fma(A[idx], x[col_of<IMP>(cols, n, Nw, mask, s, i)], acc);
-        }
+        for (int s = 1; s < W; ++s) acc = fma(op.a(s, i), x[col_of<IMP>(cols, n, Nw, mask, s, i)], acc);
         double r = -acc + (rhs ? rhs[i] : 0.0);
         rdu[i] = r;
         ulow[i] = xi;               // stable home of u_L for the flux/limit kernels
         y1[i] = omega1 * (r / (md_scale * M[i]));
     }
+}
+
+template <int WT, int BS, int IMP>
+__global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, MatRef A_ref,
+                           VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
+                           const double* __restrict__ xa_, const double* __restrict__ xb_,
+                           double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
+                           double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, int part_count,
+                           int iters_per_unit, double rel_tol, double md_scale, double omega1,
+                           const double* __restrict__ partk, int exact_k) {
+    dudt_rhs_body<WT, BS, IMP>(n, Wrt, Nw, cols, MatOp{mat_ptr(A_ref, blockIdx.y), n}, rhs_ref, rhs_bstride, M, xa_, xb_,
+                               ulow_, rdu_, y1_, part, ctl_, budget, part_count, iters_per_unit, rel_tol, md_scale, omega1,
+                               partk, exact_k);
+}
+
+template <int BS>
+__global__ void __launch_bounds__(BS) k_dudt_rhs_sb(int n, int Nw, double h, SbOpArgs sb,
+                           VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
+                           const double* __restrict__ xa_, const double* __restrict__ xb_,
+                           double* __restrict__ ulow_, double* __restrict__ rdu_, double* __restrict__ y1_,
+                           double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, int part_count,
+                           int iters_per_unit, double rel_tol, double md_scale, double omega1,
+                           const double* __restrict__ partk, int exact_k) {
+    SbOp<false> op;
+    op.p = sb; op.c = vec_ptr(sb.c) + blockIdx.y * sb.c_bstride; op.n = n; op.Nw = Nw; op.h = h;
+    dudt_rhs_body<7, BS, 1>(n, 7, Nw, nullptr, op, rhs_ref, rhs_bstride, M, xa_, xb_, ulow_, rdu_, y1_, part, ctl_, budget,
+                            part_count, iters_per_unit, rel_tol, md_scale, omega1, partk, exact_k);
 }
 
 // ---------------------------------------------------------------------------
@@ -490,10 +587,30 @@ int femfct_enqueue_step_ref(femfct_ctx* ctx, const double* A, const double* N, i
                                    u_bstride, dt, u_out, out_bstride, batch, budget);
 }
 
-// A: the flux matrix of this step, possibly one of a pre-assembled per-level sequence (MatRef)
+int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const double* N, int32_t nshared, VecRef rhs,
+                           int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
+                           int64_t out_bstride, int32_t batch, int32_t budget);
+
+// the drift-control operator may be derived inside the step kernels instead of being passed as a matrix
+bool femfct_inline_ops_wanted(const femfct_ctx* ctx, int32_t batch) {
+    return ctx->inline_ops && ctx->structured && ctx->implicit_cols && ctx->W == 7 && ctx->solver == FEMFCT_SOLVER_JACOBI &&
+           femfct_tile4_wanted(ctx, batch);
+}
+
 int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t nshared, VecRef rhs,
                             int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
                             int64_t out_bstride, int32_t batch, int32_t budget) {
+    return femfct_enqueue_step_op(ctx, A, nullptr, N, nshared, rhs, rhs_bstride, u_n, u_bstride, dt, u_out, out_bstride, batch,
+                                  budget);
+}
+
+// A: the flux matrix of this step, possibly one of a pre-assembled per-level sequence (MatRef); or sb != null
+// (only with femfct_inline_ops_wanted): the solid-body operator, derived in k_build_low_sb / k_dudt_rhs_sb
+int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const double* N, int32_t nshared, VecRef rhs,
+                           int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out,
+                           int64_t out_bstride, int32_t batch, int32_t budget) {
+    if (sb && (!femfct_inline_ops_wanted(ctx, batch) || N))
+        return femfct_fail(ctx, FEMFCT_ERR_INVALID, "inline solid-body operator outside its regime");
     LaunchGeom g = femfct_geom(ctx, batch);
     hipStream_t st = ctx->stream;
     int n = ctx->n, W = ctx->W;
@@ -508,9 +625,16 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
     // latency regime: the operator construction rides in the first tile-Jacobi launch
     const bool fused_build = ctx->fuse_build && tiles && !tile4 && !femfct_tile_big(ctx, tp) &&
                              ctx->solver != FEMFCT_SOLVER_BICGSTAB && (budget + tp.K - 1) / tp.K >= 2;
-    if (!fused_build)
+    unsigned long long* lmask = (tile4 && ctx->l_mask && ctx->t4_dpp && W == 7) ? ctx->d_Lmask + 1 : nullptr;
+    if (sb) {
+        femfct_prof_begin(ctx, KC_BUILD_LOW);
+        hipLaunchKernelGGL((k_build_low_sb<256>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, u_n, rhs_bstride,
+                           u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl, lmask);
+        femfct_prof_end(ctx);
+    } else if (!fused_build)
         LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n,
-                 rhs_bstride, u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl);
+                 rhs_bstride, u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl,
+                 lmask);
     if (ctx->solver == FEMFCT_SOLVER_BICGSTAB) {
         // robust alternative for operators far from diagonal dominance: Jacobi-preconditioned BiCGStab
         // from x0 = u^n into d_xa; outcome mirrored into StepCtl (done, parity 0)
@@ -531,7 +655,7 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
         ipu = k4;
         for (int s = 0; s < units; ++s)
             femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch, h4, k4,
-                                        single ? 2 : 0);
+                                        single ? 2 : 0, (ctx->l_mask && ctx->t4_dpp && W == 7) ? ctx->d_Lmask + 1 : nullptr);
     } else if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
@@ -576,9 +700,17 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
             return femfct_fail(ctx, FEMFCT_ERR_INVALID, "fused Chebyshev tail: nothing left to fuse");
         }
     } else {
-        LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow,
-                 ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol, 1.25, 1.0,
-                 exact_k ? ctx->d_partk : nullptr, exact_k);
+        if (sb) {
+            femfct_prof_begin(ctx, KC_DUDT_RHS);
+            hipLaunchKernelGGL((k_dudt_rhs_sb<256>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, rhs_bstride,
+                               ctx->d_M, ctx->d_xa, ctx->d_xb, ulow, ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units,
+                               part_count, ipu, ctx->rel_tol, 1.25, 1.0, (const double*)nullptr, 0);
+            femfct_prof_end(ctx);
+        } else {
+            LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa,
+                     ctx->d_xb, ulow, ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units, part_count, ipu, ctx->rel_tol,
+                     1.25, 1.0, exact_k ? ctx->d_partk : nullptr, exact_k);
+        }
         femfct_enqueue_cheb(ctx, ctx->d_rdu, ctx->d_du, 20, 0.5, 2.0, batch, true);
     }
     if (step_done) {

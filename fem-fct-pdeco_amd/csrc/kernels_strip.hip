@@ -1455,17 +1455,42 @@ __device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H) {
 // MODE 0: residual partials reduced by the next launch's workgroups; 1: more workgroups than in-kernel partials
 // (separate k_reduce_resid); 2: ONE workgroup covers the whole mesh and stops by itself (check_every > 0) -- its own
 // instantiation so that the multi-patch bandwidth kernels carry neither the branch nor its block reduction.
+// A launch of the 64-patch kernels is a matrix-load phase (HBM bound, ~2/3 of the time) followed by a register-resident
+// sweep phase (VALU bound) with one workgroup per CU, so the two phases of a CU never overlap -- and since every CU
+// starts together, all CUs load together and sweep together: HBM idles during the sweeps, the VALUs during the loads.
+// Holding back HALF of the first round's workgroups by about one load phase puts the two halves of the chip in
+// opposite phases for the rest of the launch (every workgroup takes the same time, so the offset persists): one half
+// streams at up to twice its share of HBM while the other computes.  `stagger` = (ticks of the 100 MHz constant
+// clock) | (bit << 24): the workgroups of the first round (linear index < 256) whose index has `bit` set are held
+// (dispatch order deals consecutive workgroups round-robin over the 8 XCDs, so bits 0-2 select XCDs and bits 3-7
+// step through an XCD's 32 CUs; bit 7 = the second half of every XCD).
+// Placement only affects speed, never results; the wait is bounded (every wave leaves after `ticks`).
+__device__ __forceinline__ void stagger_first_round(int stagger) {
+    if (stagger <= 0) return;
+    const unsigned wgl = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wgl >= 256u) return;
+    const int pat = stagger >> 24, ticks = stagger & 0xffffff;
+    // pat < 8: two groups by one index bit; pat >= 8: (pat - 6) groups of CU quads, group g held g * ticks
+    const int mult = pat < 8 ? (int)((wgl >> pat) & 1u) : (int)((wgl >> 5) % (unsigned)(pat - 6));
+    if (mult == 0) return;
+    const int64_t wait = (int64_t)ticks * mult;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < wait) __builtin_amdgcn_s_sleep(16);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                 double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-                int g_build, double rel_tol, double* __restrict__ bigpart, int H, int check_every) {
+                int g_build, double rel_tol, double* __restrict__ bigpart, int H, int check_every, int stagger,
+                const unsigned long long* __restrict__ lmask) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     __shared__ double smem[32];
     const int bz = blockIdx.z;
     StepCtl* ctl = ctl_ + bz;
     if (ctl->done) return;
+    stagger_first_round(stagger);
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
     double bnorm;
@@ -1497,20 +1522,53 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     Strip4Node g[4];
     // rows pre-scaled by 1 / l_ii: x_new = bs - sum ls * x_nb;  residual of the input iterate = l_ii |x_new - x|
     double lv[4][W - 1], dg[4], bv[4], x[4];
+    // Zero masks (k_build_low: bit i of slot s = l_(i,s) != 0, stored [word][slot]): a lane whose entry is exactly
+    // zero reads one shared zero word instead of its own, so a 128-byte line of L whose 16 entries all vanish is never
+    // requested.  Each lane fetches the six mask words of its node's 64-group (48 contiguous bytes, the same two
+    // addresses across the wave: cache hits), folds them into six bits, then issues its row loads; nothing waits on
+    // a value of L until all four rows are in flight.
+    const int nwords = (n + 63) >> 6;
+    const double* zero = reinterpret_cast<const double*>(lmask) - 1;   // the word in front of the masks holds 0
+    const int64_t zoff = zero - L;                                     // (flat global address space)
+    unsigned nzbits[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { g[r] = strip4_node(N, r, H); nzbits[r] = 0x3fu; }
+    if (lmask) {
+        unsigned long long mw[4][W - 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {      // all 12 (16-byte) mask loads first: one round trip, not four
+            const unsigned long long* src = lmask + ((int64_t)bz * nwords + (g[r].i >> 6)) * (W - 1);
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) mw[r][s] = src[s];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int s = 0; s < W - 1; ++s) bits |= (unsigned)((mw[r][s] >> (g[r].i & 63)) & 1ull) << s;
+            nzbits[r] = bits;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        g[r] = strip4_node(N, r, H);
-        dg[r] = 1.0; bv[r] = 0.0; x[r] = 0.0;
+        const int i = g[r].i;              // lanes outside the mesh read node 0's (finite) data and are zeroed below
+        dg[r] = L[i];
 #pragma unroll
-        for (int s = 0; s < W - 1; ++s) lv[r][s] = 0.0;
-        if (g[r].inside) {
-            dg[r] = L[g[r].i];
-            const double rdg = 1.0 / dg[r];
-#pragma unroll
-            for (int s = 1; s < W; ++s) lv[r][s - 1] = L[(int64_t)s * n + g[r].i] * rdg;
-            bv[r] = b_[voff + g[r].i] * rdg;
-            x[r] = xin[g[r].i];
+        for (int s = 1; s < W; ++s) {
+            const int64_t off = ((nzbits[r] >> (s - 1)) & 1u) ? (int64_t)s * n + i : zoff;   // one load either way
+            lv[r][s - 1] = L[off];
         }
+        bv[r] = b_[voff + i];
+        x[r] = xin[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double rdg = 1.0 / dg[r];
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s) lv[r][s] = g[r].inside ? lv[r][s] * rdg : 0.0;
+        bv[r] = g[r].inside ? bv[r] * rdg : 0.0;
+        x[r] = g[r].inside ? x[r] : 0.0;
+        dg[r] = g[r].inside ? dg[r] : 1.0;
     }
     double rmax = 0.0;
     for (int k = 0; k < K; ++k) {
@@ -1746,7 +1804,7 @@ int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
 }
 
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch, int H, int K, int check_every) {
+                                int g_build, int32_t batch, int H, int K, int check_every, const unsigned long long* lmask) {
     const int t = femfct_tile4_tiles(ctx, H);
     const bool big = (int64_t)t * t > FEMFCT_MAX_PARTIALS;
     dim3 grid(t, t, batch);
@@ -1755,15 +1813,16 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     if (ctx->t4_dpp) {
         if (big) {
             hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every, (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask);
             hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                                ctx->d_ctl, launch);
         } else if (check_every > 0) {
             hipLaunchKernelGGL(k_strip4_jacobi<2>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every, 0, lmask);
         } else {
             hipLaunchKernelGGL(k_strip4_jacobi<0>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, 0);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, 0,
+                               (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask);
         }
     } else if (big) {
         hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,

@@ -13,6 +13,7 @@
 #include "device_utils.h"
 #include "forms.h"
 #include "traj_common.h"
+#include "solidbody_op.h"
 
 #include <algorithm>
 
@@ -161,20 +162,24 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
     MatRef Aall{};
     bool pre = false;
     // step k (level counter k) uses the control of level k+1 (finaltime.py:185): sequence entry k
+    // bandwidth regime: the step kernels derive the operator from Arot and the control themselves (no stored A)
+    const bool inl = femfct_inline_ops_wanted(ctx, batch);
     auto begin = [&]() {
-        pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 1, eps, -1.0, rot_scale, bx, by, num_steps, batch,
-                                    &Aall);
+        if (!inl)
+            pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 1, eps, -1.0, rot_scale, bx, by, num_steps,
+                                        batch, &Aall);
         return FEMFCT_OK;
     };
     auto step = [&](int budget, int, int reps) {
         femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
                                  key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol),
-                                 key_bits(pre ? Aall.base : nullptr), key_bits(src_traj)};
+                                 key_bits(pre ? Aall.base : nullptr), key_bits(src_traj), key_bits((int32_t)inl)};
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
             MatRef A = Aall;
-            if (!pre) {
+            const SbOpArgs sb{Arot, ctx->d_Ad, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0, rot_scale, bx, by};
+            if (!pre && !inl) {
                 femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
                                              rot_scale, bx, by, ctx->d_trA, batch);
                 A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
@@ -185,9 +190,9 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
                 rhs = make_ref(ctx->d_trRhs);
             }
             femfct_request_fused_end(ctx, 1, false);
-            int r = femfct_enqueue_step_mat(ctx, A, nullptr, 0, rhs, n,
-                                            make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
-                                            tstride, batch, budget);
+            int r = femfct_enqueue_step_op(ctx, A, inl ? &sb : nullptr, nullptr, 0, rhs, n,
+                                           make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
+                                           tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
             femfct_enqueue_step_end(ctx, 1, batch, false);
             return FEMFCT_OK;
@@ -210,10 +215,12 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
     int32_t* lv = ctx->d_level;
     MatRef Aall{};
     bool pre = false;
+    const bool inl = femfct_inline_ops_wanted(ctx, batch);
     auto begin = [&]() {
         // level counter n uses the control of level n (finaltime.py:213): sequence entry n
-        pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 0, eps, +1.0, rot_scale, bx, by, num_steps, batch,
-                                    &Aall);
+        if (!inl)
+            pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 0, eps, +1.0, rot_scale, bx, by, num_steps,
+                                        batch, &Aall);
         // terminal condition: p(T) = uhat_T - u(T) (finaltime.py:201) or 0 (alltime.py:232)
         for (int32_t b = 0; b < batch; ++b) {
             double* pT = p_traj + b * tstride + (int64_t)num_steps * n;
@@ -226,11 +233,13 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
         femfct_ctx::GraphKey key{(uint64_t)3, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(uhat), key_bits(p_traj), key_bits(num_steps), key_bits(dt), key_bits(eps),
                                  key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
-                                 key_bits((int32_t)budget), key_bits(ctx->rel_tol), key_bits(pre ? Aall.base : nullptr)};
+                                 key_bits((int32_t)budget), key_bits(ctx->rel_tol), key_bits(pre ? Aall.base : nullptr),
+                                 key_bits((int32_t)inl)};
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
             // level counter = n: control c_n (finaltime.py:213), p_{n+1} -> p_n
             MatRef A = Aall;
-            if (!pre) {
+            const SbOpArgs sb{Arot, ctx->d_Ad, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0, rot_scale, bx, by};
+            if (!pre && !inl) {
                 femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
                                              rot_scale, bx, by, ctx->d_trA, batch);
                 A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
@@ -242,8 +251,8 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
                 rhs = make_ref(ctx->d_trRhs);
             }
             femfct_request_fused_end(ctx, -1, false);
-            int r = femfct_enqueue_step_mat(ctx, A, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
-                                            dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
+            int r = femfct_enqueue_step_op(ctx, A, inl ? &sb : nullptr, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
+                                           dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
             femfct_enqueue_step_end(ctx, -1, batch, false);
             return FEMFCT_OK;

@@ -21,6 +21,11 @@ int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t 
                             int32_t budget);
 int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
                          double* out);
+struct SbOpArgs;
+bool femfct_inline_ops_wanted(const femfct_ctx* ctx, int32_t batch);
+int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const double* N, int32_t nshared, VecRef rhs,
+                           int64_t rhs_bstride, VecRef u_n, int64_t u_bstride, double dt, VecRef u_out, int64_t out_bstride,
+                           int32_t batch, int32_t budget);
 
 static inline int femfct_round_kry_budget(const femfct_ctx* ctx, int b) {
     b = (b + 3) & ~3;

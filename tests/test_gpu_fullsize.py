@@ -223,3 +223,35 @@ def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
         assert eu < 1e-9 and ep < 1e-9
     finally:
         prob.close()
+
+
+def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch):
+    """Two traffic savers of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
+    operator derived inside k_build_low_sb / k_dudt_rhs_sb instead of stored by k_ops_solidbody and read back;
+    (ii) FEMFCT_LMASK -- the exactly-zero off-diagonals of the upwind low-order operator skipped when the Jacobi
+    patches load L.  Forward + all-time adjoint (source term) at 331^2 nodes, eps != 0 as well."""
+    nc, Nt = 330, 2
+    mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
+    n = mesh.nodes
+    dt = 1e-3 * (2.0 / nc) / 0.025
+    x, y = mesh.coordinates()
+    rng = np.random.default_rng(17)
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1) + 0.1 * rng.random((Nt + 1) * n)
+    for eps in (0.0, 1e-3):
+        outs = []
+        for inline_ops, lmask in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+            monkeypatch.setenv("FEMFCT_INLINE_OPS", inline_ops)
+            monkeypatch.setenv("FEMFCT_LMASK", lmask)
+            prob = solvers.SolidBodyDrift(mesh, Nt, dt, eps=eps, order=hp.ORDER_VERTEX)
+            try:
+                assert prob.ctx.uses_bandwidth_tiles(1)
+                uk = np.zeros((Nt + 1) * n)
+                uk[:n] = u0
+                prob.solve_state(c, uk)
+                pk = prob.solve_adjoint(c, uk, 0.9 * uk + 0.01, np.zeros_like(uk), optim="alltime")
+                outs.append((uk.copy(), pk.copy()))
+            finally:
+                prob.close()
+        for uk, pk in outs[1:]:
+            assert np.array_equal(uk, outs[0][0]) and np.array_equal(pk, outs[0][1])
