@@ -59,13 +59,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s is ach
 # vertex order: index-free addressing, no column-index bytes; ELL width 7 = diagonal + 6).  Every
 # array a launch reads or writes is counted once, whatever the number of sweeps it performs.
 # ---------------------------------------------------------------------------------------------
-def launch_bytes_per_row(fused: bool, geom_mass: bool):
+def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False):
     b = {
         "assemble": 7 * 8 * 3 + 6 * 4 + 8,          # Ad, Arot, A(write), neighbour indices, c   (per level)
         "build_low": 7 * 8 * 3 + 8 * 4,             # A, L(w), D(w), ml, u_n, b(w), x0(w)
-        "jacobi": 7 * 8 + 8 * 3,                    # L, b, x_in, x_out(w)
+        "jacobi": 7 * 8 + 8 * 3,                    # L, b, x_in, x_out(w)  (all of L: the zero mask is not credited)
         "dudt_rhs": 7 * 8 + 8 * 5,                  # A, u_L, M_diag, r(w), u_L copy(w), y1(w)
     }
+    if inline_ops:                                  # operator derived in the kernels from Arot + the control's 1-ring
+        b["build_low"] = 7 * 8 * 3 + 8 * 5 + 1      # Arot, L(w), D(w), c, ml, u_n, b(w), x0(w), zero mask(w)
+        b["dudt_rhs"] = 7 * 8 + 8 * 6               # Arot, c, u_L, M_diag, r(w), u_L copy(w), y1(w)
     if fused:
         b["cheb"] = 8 * 4 + (0 if geom_mass else 7 * 8)            # b, y_mid, y_old|y_old(w), y_new(w) [+ M]
         b["flux"] = 6 * 8 + 8 * 4 + (0 if geom_mass else 6 * 8)     # D, u_L, du, ml, u_out(w) [+ M]: F never stored
@@ -462,7 +465,8 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     # ---- (1) the product path at this size (fused multi-sweep kernels)
     step_ms, rep, sweeps = _profiled_forward(prob, ctx, d_c, d_u, steps)
     fused_flux = rep["limit"][1] == 0
-    bpr = launch_bytes_per_row(fused=regime >= 2 and fused_flux, geom_mass=geom)
+    inline_ops = rep["assemble"][1] == 0           # no stored operator: k_build_low_sb / k_dudt_rhs_sb
+    bpr = launch_bytes_per_row(fused=regime >= 2 and fused_flux, geom_mass=geom, inline_ops=inline_ops)
     units = {"assemble": steps}
     one_sweep_units = {"jacobi": sweeps, "cheb": 19 * steps, "flux": steps}
     kernels = _kernel_table(rep, bpr, n, units, traffic, one_sweep_units)
@@ -485,6 +489,7 @@ def roofline(hp, solvers, n_cells, steps, device_id):
            "workload": f"synthetic square mesh {n_cells + 1}x{n_cells + 1} (n={n}), vertex order, same CFL as C2",
            "compulsory_bytes_per_launch": dom["compulsory_bytes_per_row_per_launch"] * n,
            "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "source_sha16": sha,
+           "operator": "derived inside k_build_low_sb / k_dudt_rhs_sb" if inline_ops else "stored by k_ops_solidbody",
            "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms, "jacobi_sweeps_per_step": sweeps / steps,
            "step": {"compulsory_bytes": step_bytes, "compulsory_GBps": step_bytes / (1e6 * step_ms),
                     "compulsory_frac": step_bytes / (1e6 * step_ms) / HBM_PEAK_GBS,

@@ -23,7 +23,8 @@ from .systems import (  # noqa: F401
     solve_adjoint_schnak_system, solve_chtxs_system, solve_adjoint_chtxs_system,
     get_schnak_sys_params, get_nonlinear_eqns_params, get_chtxs_sys_params,
     schnak_sys_IC, nonlinear_equation_IC, chtxs_sys_IC, armijo_line_search_ref, assemble_mass)
-from .data_io import import_data_final, extract_data, save_trajectory  # noqa: F401
+from .data_io import (import_data_final, extract_data, save_trajectory, save_results,  # noqa: F401
+                      append_results_ledger)
 from .pdeco import projected_gradient_descent, SystemPDECO  # noqa: F401
 from . import fct_helpers, systems, solvers, sweep, data_io, pdeco  # noqa: F401
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     "femfct_last_step_info": (C.c_int, [_p, C.POINTER(StepInfo), _i]),
     "femfct_fct_step_host": (C.c_int, [_p, _p, _p, _p, _p, _d, _p, C.POINTER(StepInfo)]),
     "femfct_chebsi": (C.c_int, [_p, _p, _p, _i, _d, _d, _i]),
+    "femfct_chebsi_md": (C.c_int, [_p, _p, _p, _p, _i, _d, _d, _i]),
     "femfct_artificial_diffusion": (C.c_int, [_p, _p, _p, _i]),
     "femfct_spmv": (C.c_int, [_p, _p, _p, _d, _d, _p, _i]),
     "femfct_mesh_quad_points": (C.c_int, [_p, _p, _p]),

@@ -13,7 +13,7 @@ int femfct_enqueue_artdiff(femfct_ctx* ctx, const double* K, double* D, int32_t 
 int femfct_enqueue_spmv(femfct_ctx* ctx, const double* A, const double* x, double alpha, double beta, double* y,
                         int32_t batch);
 int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int iters, double lmin, double lmax,
-                        int32_t batch, bool first_done_in_y1);
+                        int32_t batch, bool first_done_in_y1, const double* mdv = nullptr);
 int femfct_mesh_release(femfct_ctx* ctx);
 int femfct_build_structured_csr(femfct_ctx* ctx);  // mesh.hip
 
@@ -643,6 +643,16 @@ int femfct_chebsi(femfct_ctx* ctx, const double* b_dev, double* y_dev, int32_t c
     int rc = femfct_ensure_workspace(ctx, batch);
     if (rc != FEMFCT_OK) return rc;
     return femfct_enqueue_cheb(ctx, b_dev, y_dev, cheb_iter, lmin, lmax, batch, false);
+}
+
+int femfct_chebsi_md(femfct_ctx* ctx, const double* b_dev, double* y_dev, const double* md_dev, int32_t cheb_iter,
+                     double lmin, double lmax, int32_t batch) {
+    FEMFCT_ENTER(ctx);
+    ARG_TRY(ctx, ctx && ctx->n > 0 && ctx->have_mass, "mass matrix not set");
+    ARG_TRY(ctx, b_dev && y_dev && md_dev && cheb_iter >= 1 && batch == 1 && lmin + lmax != 0, "bad argument");
+    int rc = femfct_ensure_workspace(ctx, batch);
+    if (rc != FEMFCT_OK) return rc;
+    return femfct_enqueue_cheb(ctx, b_dev, y_dev, cheb_iter, lmin, lmax, batch, false, md_dev);
 }
 
 int femfct_artificial_diffusion(femfct_ctx* ctx, const double* K_ell, double* D_ell, int32_t batch) {

@@ -347,7 +347,8 @@ template <int WT, int BS, int IMP>
 __global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, int Nw, const int32_t* __restrict__ cols, const double* __restrict__ M,
                        const double* __restrict__ b_, const double* __restrict__ ymid_,
                        const double* __restrict__ yold_, double* __restrict__ ynew_, double omega,
-                       double md_scale) {
+                       double md_scale, const double* __restrict__ mdv) {
+    // mdv: the caller's own preconditioner diagonal Md (ChebSI's third argument) when it is not diag(M)
     const int W = WT ? WT : Wrt;
     const int64_t voff = (int64_t)blockIdx.y * n;
     const double* b = b_ + voff;
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(BS) k_cheb(int n, int Wrt, int Nw, const int32
             }
         }
         double r = b[i] - acc;
-        double z = r / (md_scale * md);
+        double z = r / (md_scale * (mdv ? mdv[i] : md));
         double yo = yold ? yold[i] : 0.0;
         ynew[i] = omega * (z + ym - yo) + yo;
     }
@@ -533,12 +534,23 @@ static void cheb_omegas(int iters, double lmin, double lmax, std::vector<double>
     } while (0)
 
 int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int iters, double lmin, double lmax,
-                        int32_t batch, bool first_done_in_y1) {
+                        int32_t batch, bool first_done_in_y1, const double* mdv = nullptr) {
     // rotating buffers y0,y1,y2; iterate k reads mid=buf[(k-1)%3], old=buf[(k-2)%3], writes buf[k%3]
     LaunchGeom g = femfct_geom(ctx, batch);
     std::vector<double> om;
     cheb_omegas(iters, lmin, lmax, om);
     const double md_scale = (lmin + lmax) / 2.0;
+    if (mdv) {   // a preconditioner diagonal of the caller's: the one-sweep row kernels take it as a vector
+        double* bufv[3] = {ctx->d_y0, ctx->d_y1, ctx->d_y2};
+        for (int k = 1; k <= iters; ++k) {
+            const double* mid = (k >= 2) ? bufv[(k - 1) % 3] : nullptr;
+            const double* old = (k >= 3) ? bufv[(k - 2) % 3] : nullptr;
+            double* out = (k == iters) ? y_out : bufv[k % 3];
+            LAUNCH_W(KC_CHEB, k_cheb, g, ctx->stream, ctx->n, ctx->W, ctx->N, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1],
+                     md_scale, mdv);
+        }
+        return FEMFCT_OK;
+    }
     if (femfct_tile4_wanted(ctx, batch)) {
         if (first_done_in_y1)
             return femfct_enqueue_tile4_cheb(ctx, b, ctx->d_y1, nullptr, y_out, 2, iters, om.data(), md_scale, ctx->d_y0,
@@ -570,7 +582,8 @@ int femfct_enqueue_cheb(femfct_ctx* ctx, const double* b, double* y_out, int ite
         const double* mid = (k >= 2) ? buf[(k - 1) % 3] : nullptr;
         const double* old = (k >= 3) ? buf[(k - 2) % 3] : nullptr;
         double* out = (k == iters) ? y_out : buf[k % 3];
-        LAUNCH_W(KC_CHEB, k_cheb, g, ctx->stream, n, W, ctx->N, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale);
+        LAUNCH_W(KC_CHEB, k_cheb, g, ctx->stream, n, W, ctx->N, ctx->d_cols, ctx->d_M, b, mid, old, out, om[k - 1], md_scale,
+                 (const double*)nullptr);
     }
     return FEMFCT_OK;
 }

@@ -238,6 +238,11 @@ class Context:
         check(self.handle, lib.femfct_chebsi(self.handle, dptr(b), dptr(y), int(cheb_iter), float(lmin),
                                              float(lmax), int(batch)))
 
+    def chebsi_md(self, b, y, md, cheb_iter=20, lmin=0.5, lmax=2.0):
+        """ChebSI with a preconditioner diagonal of the caller's (not diag(M)); one system."""
+        check(self.handle, lib.femfct_chebsi_md(self.handle, dptr(b), dptr(y), dptr(md), int(cheb_iter), float(lmin),
+                                                float(lmax), 1))
+
     def artificial_diffusion(self, K_ell, D_ell, batch=1):
         check(self.handle, lib.femfct_artificial_diffusion(self.handle, dptr(K_ell), dptr(D_ell), int(batch)))
 

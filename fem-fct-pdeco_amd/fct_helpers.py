@@ -152,22 +152,30 @@ def FCT_alg(A, rhs, u_n, dt, nodes, M, M_lumped, dof_neighbors, source_mat=None)
 
 
 def ChebSI(vec, M, Md, cheb_iter=20, lmin=0.5, lmax=2):
-    """Chebyshev semi-iteration for ``M x = vec`` (helpers.py:143-185).  ``Md`` must be the
-    diagonal of ``M`` (the only way the reference calls it: helpers.py:1815)."""
+    """Chebyshev semi-iteration for ``M x = vec`` (helpers.py:143-185).  ``Md`` is the preconditioner diagonal:
+    ``M.diagonal()`` in every call the reference makes (helpers.py:1815; fused multi-sweep kernels), any other
+    positive vector goes through the one-sweep kernels with ``Md`` as a device vector."""
     pat = _PatternCache.get_for(M)
-    md = np.asarray(Md, dtype=np.float64).ravel()
-    if md.shape[0] != pat.n or not np.array_equal(md, _diag(M)):
-        raise ValueError("ChebSI: Md must equal M.diagonal()")
+    md = np.ascontiguousarray(Md, dtype=np.float64).ravel()
+    if md.shape[0] != pat.n:
+        raise ValueError(f"ChebSI: Md has {md.shape[0]} entries, M has {pat.n} rows")
     pat.set_mass(M, np.asarray(csr_matrix(M).sum(axis=1)).ravel())
     ctx = pat.ctx
     b = ctx.array(np.asarray(vec, dtype=np.float64).ravel())
     y = ctx.empty(pat.n)
+    mdd = None
     try:
-        ctx.chebsi(b, y, cheb_iter, lmin, lmax)
+        if np.array_equal(md, _diag(M)):
+            ctx.chebsi(b, y, cheb_iter, lmin, lmax)
+        else:
+            mdd = ctx.array(md)
+            ctx.chebsi_md(b, y, mdd, cheb_iter, lmin, lmax)
         return y.download()
     finally:
         b.free()
         y.free()
+        if mdd is not None:
+            mdd.free()
 
 
 def artificial_diffusion_mat(mat):

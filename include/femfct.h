@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FEMFCT_ABI_VERSION 3   /* 3: femfct_kernel_regime; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
+#define FEMFCT_ABI_VERSION 3   /* 3: femfct_kernel_regime, femfct_chebsi_md; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
 
 typedef struct femfct_ctx femfct_ctx;
 
@@ -154,6 +154,10 @@ int femfct_fct_step_host(femfct_ctx* ctx, const double* A_csr_vals, const double
  * Md = its diagonal). */
 int femfct_chebsi(femfct_ctx* ctx, const double* b_dev, double* y_dev, int32_t cheb_iter,
                   double lmin, double lmax, int32_t batch);
+/* The same with a caller-supplied preconditioner diagonal Md != diag(M) (third argument of ChebSI, helpers.py:143,
+ * 181-182: z = r / (Md * (lmin+lmax)/2)); one system per call (batch must be 1), one-sweep row kernels. */
+int femfct_chebsi_md(femfct_ctx* ctx, const double* b_dev, double* y_dev, const double* md_dev, int32_t cheb_iter,
+                     double lmin, double lmax, int32_t batch);
 /* artificial_diffusion_mat(mat)  helpers.py:206-242: D_ell from K_ell (diagonal included) */
 int femfct_artificial_diffusion(femfct_ctx* ctx, const double* K_ell, double* D_ell, int32_t batch);
 /* y = alpha * Mat * x + beta * y  with an ELL matrix on the registered pattern */

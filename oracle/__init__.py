@@ -1,6 +1,6 @@
 """CPU oracle for the FEM-FCT forward/adjoint time-stepping path.
 
-TEST INFRASTRUCTURE ONLY.  This package is a CPU (NumPy/SciPy + plain C)
+TEST INFRASTRUCTURE ONLY.  This package is a CPU (NumPy/SciPy; no compiled part)
 restatement of the reference algorithm (KarolinaBenkova/FEM-FCT-PDECO,
 ``helpers.py``).  It exists to *check* the HIP product path, never to be it:
 
@@ -9,7 +9,7 @@ restatement of the reference algorithm (KarolinaBenkova/FEM-FCT-PDECO,
   * the product package (``fem-fct-pdeco_amd/``) never imports it and fails
     loudly when its HIP library is missing.
 
-Parity status: PINNED.
+Parity status: PINNED, except the adjoint chemotaxis exp-forms (last item).
   * ``oracle.fct`` (FCT step, ChebSI, artificial diffusion, norms, cost
     functional) is checked against the reference's own functions imported in
     the build container (``tests/golden/make_golden.py`` generated the

@@ -20,6 +20,11 @@ Files written
   solidbody_traj_N21.npz   20 forward + 20 adjoint reference FCT steps, drift control
   chtxs_fenics_traj.npz    Chtxs_data_dx0.025_dt0.001/chtxs_{m,f}_t0.01.csv (real FEniCS)
   solidbody_t0.25_u.npz    data/solidbody_t0.25_u.csv (PDECO target, an input)
+  ref_data/                (``--io-only`` regenerates just these) two of the reference's DATA files in the
+                           reference's own on-disk format -- data/solidbody_t0.25_u.csv whole, the first three
+                           time levels of Chtxs_data_dx0.025_dt0.001/chtxs_m_t0.01.csv (a byte prefix cut at a
+                           comma) -- plus what the REAL import_data_final / extract_data (helpers.py:1874-1956)
+                           return / write for them: io_ref.npz, chtxs_m_3levels_T0.002.csv
 """
 import io
 import os
@@ -273,5 +278,38 @@ def main():
     print("done")
 
 
+def data_io_fixtures(hp=None):
+    """Reference-written data files + the reference's own readers' outputs (host I/O compatibility)."""
+    import shutil
+    hp = hp or import_reference()
+    from oracle.mesh import SquareMesh
+    out = os.path.join(HERE, "ref_data")
+    os.makedirs(out, exist_ok=True)
+    # (1) final-time target of config C2, exactly as the reference ships it
+    src = os.path.join(REF, "data/solidbody_t0.25_u.csv")
+    shutil.copyfile(src, os.path.join(out, "solidbody_t0.25_u.csv"))
+    os.chmod(os.path.join(out, "solidbody_t0.25_u.csv"), 0o644)
+    v2d81 = SquareMesh(-1, 1, 80).vertex_to_dof
+    re81, d81 = hp.import_data_final(src, 6561, v2d81)
+    # (2) a trajectory file: first 3 levels (3 * 1681 values) of the real-FEniCS chemotaxis trajectory, bytes untouched
+    raw = open(os.path.join(REF, "Chtxs_data_dx0.025_dt0.001/chtxs_m_t0.01.csv"), "rb").read()
+    pos = -1
+    for _ in range(3 * 1681):
+        pos = raw.index(b",", pos + 1)
+    open(os.path.join(out, "chtxs_m_3levels.csv"), "wb").write(raw[:pos])
+    v2d41 = SquareMesh(0, 1, 40).vertex_to_dof
+    traj = os.path.join(out, "chtxs_m_3levels.csv")
+    re_td, d_td = hp.import_data_final(traj, 1681, v2d41, num_steps=2, time_dep=True)
+    re_l1, d_l1 = hp.import_data_final(traj, 1681, v2d41, num_steps=1)
+    # (3) the reference's extract_data on it (writes <name>_T<T>.csv next to the input)
+    quiet(hp.extract_data, out, "chtxs_m_3levels", 0.002, 0.001, 1681, v2d41)
+    np.savez_compressed(os.path.join(out, "io_ref.npz"), re81=re81, d81=d81, re_td=re_td, d_td=d_td, re_l1=re_l1, d_l1=d_l1)
+    print("ref_data written:", sorted(os.listdir(out)))
+
+
 if __name__ == "__main__":
-    main()
+    if "--io-only" in sys.argv:
+        data_io_fixtures()
+    else:
+        main()
+        data_io_fixtures()

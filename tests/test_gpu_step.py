@@ -99,8 +99,15 @@ def test_small_kernels(hp):
     n = M.shape[0]
     y = hp.ChebSI(z["cheb_b"], M, M.diagonal(), 20, 0.5, 2)
     assert rel(y, z["cheb_y"]) < 1e-13
+    # a preconditioner diagonal other than diag(M) (the reference's signature allows it, helpers.py:143): against
+    # the oracle's restatement of the same iteration
+    from oracle.fct import chebsi
+    rng = np.random.default_rng(2)
+    md = M.diagonal() * (1.0 + 0.3 * rng.random(n))
+    y2 = hp.ChebSI(z["cheb_b"], M, md, 12, 0.5, 2)
+    assert rel(y2, chebsi(z["cheb_b"], M, md, 12, 0.5, 2)) < 1e-13
     with pytest.raises(ValueError):
-        hp.ChebSI(z["cheb_b"], M, 2 * M.diagonal())
+        hp.ChebSI(z["cheb_b"], M, md[:-1])
     K = csr_from(z, "K", n)
     D = hp.artificial_diffusion_mat(K)
     Dref = csr_from(z, "D", n)

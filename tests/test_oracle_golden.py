@@ -131,3 +131,18 @@ def test_solidbody_trajectory_vs_reference_fct():
     pk = np.zeros((Nt + 1) * n)
     otraj.solidbody_adjoint(sb, z["ck"], uk, z["uhat"], pk, n, Nt, dt, optim="finaltime")
     assert rel(pk, z["pk"]) < 1e-11
+
+
+def test_sparse_nonzero_matches_reference():
+    """helpers.py:187-204: [row, col, value, value > 0] of every stored entry -- the product's
+    drop-in against the array the real helpers.sparse_nonzero returned for the same matrix (kernels.npz:K_nonzero)."""
+    import importlib
+    hp = importlib.import_module("fem-fct-pdeco_amd")
+    z = load("kernels.npz")
+    n = (int(z["geom"][2]) + 1) ** 2
+    K = csr_from(z, "K", n)
+    nz = hp.sparse_nonzero(K)
+    ref = z["K_nonzero"]
+    assert nz.shape == ref.shape == (K.nnz, 4)
+    assert np.array_equal(nz, ref)
+    assert set(np.unique(nz[:, 3])) <= {0.0, 1.0} and np.array_equal(nz[:, 3] == 1.0, nz[:, 2] > 0)

@@ -40,11 +40,12 @@ __device__ __forceinline__ double row_from_prev(double v) {
 // SHIFT: 0 none (uses own value), 1 wave_shl/shr DPP, 2 row_shl/shr DPP, 3 ds_bpermute
 // LDSX: 0 no LDS/barrier, 1 LDS rows + barrier (product), 2 barrier only
 template <int SHIFT, int LDSX, int ROWS, int ORDER = 0>
-__global__ void __launch_bounds__(1024) k_sweeps(const double* __restrict__ in, double* __restrict__ out, int K) {
-    __shared__ double top[2][16][64], bot[2][16][64];
+__global__ void __launch_bounds__(64 * (64 / ROWS)) k_sweeps(const double* __restrict__ in, double* __restrict__ out, int K) {
+    constexpr int NS = 64 / ROWS;   // strips (waves) per workgroup: the patch is always 64 x 64
+    __shared__ double top[2][NS][64], bot[2][NS][64];
     const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
     double lv[ROWS][6], bv[ROWS], x[ROWS];
-    const int64_t base = ((int64_t)blockIdx.x * 1024 + threadIdx.x) * ROWS;
+    const int64_t base = ((int64_t)blockIdx.x * (64 * NS) + threadIdx.x) * ROWS;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         x[r] = in[(base + r) & 0xfffff];
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(1024) k_sweeps(const double* __restrict__ in, 
         }
         if (LDSX >= 1) __syncthreads();
         if (LDSX == 1) {
-            above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+            above = (st < NS - 1) ? bot[par][st + 1][lx] : 0.0;
             below = (st > 0) ? top[par][st - 1][lx] : 0.0;
         }
         double e_[ROWS], w_[ROWS], ea_, wb_;
@@ -106,7 +107,7 @@ static void run(const char* name, const double* in, double* out, int wgs, int K)
         for (int pass = 0; pass < 2; ++pass) {
             const int kk = pass ? K : 0;
             CHECK(hipEventRecord(a, 0));
-            hipLaunchKernelGGL((k_sweeps<SHIFT, LDSX, ROWS, ORDER>), dim3(wgs), dim3(1024), 0, 0, in, out, kk);
+            hipLaunchKernelGGL((k_sweeps<SHIFT, LDSX, ROWS, ORDER>), dim3(wgs), dim3(64 * (64 / ROWS)), 0, 0, in, out, kk);
             CHECK(hipEventRecord(b, 0));
             CHECK(hipEventSynchronize(b));
             float ms; CHECK(hipEventElapsedTime(&ms, a, b));
@@ -115,7 +116,7 @@ static void run(const char* name, const double* in, double* out, int wgs, int K)
     }
     const double rounds = wgs / 256.0;
     const double us_per_wg_sweep = (best - best0) * 1e3 / K / rounds;
-    printf("%-44s K=%d: %8.3f ms (K=0: %.3f) -> %.3f us per workgroup-sweep = %.0f cycles @2.4GHz per wave-sweep (4 waves/SIMD)\n",
+    printf("%-44s K=%d: %8.3f ms (K=0: %.3f) -> %.3f us per workgroup-sweep (64x64 patch) = %.0f cycles @2.4GHz per 4 rows of one SIMD lane-set\n",
            name, K, best, best0, us_per_wg_sweep, us_per_wg_sweep * 2400.0 / 4.0);
 }
 
@@ -123,7 +124,7 @@ int main(int argc, char** argv) {
     const int wgs = 2048, K = argc > 1 ? atoi(argv[1]) : 64;
     double *in, *out;
     CHECK(hipMalloc(&in, (1 << 20) * 8));
-    CHECK(hipMalloc(&out, (size_t)wgs * 1024 * 4 * 8));
+    CHECK(hipMalloc(&out, (size_t)wgs * 4096 * 8));
     std::vector<double> h(1 << 20);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0.5 + 1e-3 * (i % 977);
     CHECK(hipMemcpy(in, h.data(), h.size() * 8, hipMemcpyHostToDevice));
@@ -136,5 +137,9 @@ int main(int argc, char** argv) {
     run<2, 0, 4>("row DPP, no LDS / barrier", in, out, wgs, K);
     run<3, 1, 4>("ds_bpermute shuffles + LDS rows + barrier", in, out, wgs, K);
     run<1, 1, 4, 1>("product, inner rows first", in, out, wgs, K);
+    run<1, 1, 8, 0>("8 rows per thread, 8 waves", in, out, wgs, K);
+    run<1, 1, 8, 1>("8 rows per thread, 8 waves, inner rows first", in, out, wgs, K);
+    run<1, 0, 8, 0>("8 rows per thread, no LDS / barrier", in, out, wgs, K);
+    run<1, 1, 16, 1>("16 rows per thread, 4 waves, inner first", in, out, wgs, K);
     return 0;
 }
