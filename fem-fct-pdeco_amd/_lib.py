@@ -116,6 +116,8 @@ SIGNATURES = {
     "femfct_nonlinear_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _i, _d, _d, _i]),
     "femfct_schnak_forward": (C.c_int, [_p, _p, _p, _p, _p, _i, _d, _p, _d, _i]),
     "femfct_schnak_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _p, _i, _i]),
+    "femfct_schnak_forward_tw": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _d, _p, _d, _i]),
+    "femfct_schnak_adjoint_tw": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _p, _i, _i]),
     "femfct_chtxs_forward": (C.c_int, [_p, _p, _p, _p, _i, _d, _p, _d, _i]),
     "femfct_chtxs_adjoint": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _d, _p, _d, _i, _i]),
     "femfct_traj_krylov_info": (C.c_int, [_p, C.POINTER(StepInfo), _i, _i]),

@@ -88,6 +88,7 @@ void femfct_release_pattern(femfct_ctx* ctx) {
     if (ctx->d_kry_ctl2) { hipFree(ctx->d_kry_ctl2); ctx->d_kry_ctl2 = nullptr; }
     if (ctx->d_klog) { hipFree(ctx->d_klog); ctx->d_klog = nullptr; }
     ctx->kry_batch = 0;
+    dev_free(&ctx->d_wscale); ctx->wscale_count = 0;
     dev_free(&ctx->d_trMat); dev_free(&ctx->d_trBase); dev_free(&ctx->d_trBase2); dev_free(&ctx->d_trRhs2); dev_free(&ctx->d_trTmp);
     ctx->implicit_cols = false;
     ctx->n = 0; ctx->W = 0; ctx->nnz_csr = 0; ctx->ws_batch = 0; ctx->have_mass = false; ctx->structured = false; ctx->mass_is_mesh = false;
@@ -230,6 +231,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_FUSE_END")) ctx->fuse_end = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
     if (const char* e = getenv("FEMFCT_LMASK")) ctx->l_mask = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_T4_XCD")) ctx->t4_xcd = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_INLINE_OPS")) ctx->inline_ops = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_STAGGER_US")) {
         const double us = atof(e);

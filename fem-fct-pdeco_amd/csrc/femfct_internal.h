@@ -75,6 +75,7 @@ struct femfct_ctx {
     bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
+    int t4_xcd = 0;             // 64-patch kernels: x-neighbouring patches under the same XCD's L2 (FEMFCT_T4_XCD)
     int t4_stagger = 600 | (7 << 24);   // 64-patch Jacobi launches of >= 4 rounds: first-round stagger, ticks of 10 ns | pattern << 24
                                         // (FEMFCT_T4_STAGGER_US / _PAT; 6 us, second half of every XCD; 0 = off)
     int tile4_mode = 1;         // 64x64-patch tiles: 0 off, 1 automatic (n*batch large), 2 always
@@ -151,6 +152,8 @@ struct femfct_ctx {
     // extra trajectory operators
     double *d_trMat = nullptr, *d_trBase = nullptr, *d_trBase2 = nullptr;  // [B*W*n], [W*n], [W*n]
     double *d_trRhs2 = nullptr, *d_trTmp = nullptr;                        // [B*n]
+    double* d_wscale = nullptr;     // per-level factors s(t_k) of a separable time-dependent wind [wscale_count]
+    size_t wscale_count = 0;
 
     // scratch for reductions (kernels_pgd.hip)
     double* d_scratch = nullptr;

@@ -1430,11 +1430,25 @@ struct Strip4Node {
     bool inside, owned;
 };
 
-__device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H) {
+// Patch of this workgroup.  remap: consecutive patches (row-major) go to workgroups of the SAME XCD -- dispatch deals
+// workgroups round-robin over the 8 XCDs, so without it two x-neighbouring patches, which share 2H of their 64
+// columns, always sit under different L2s and each XCD fetches the shared halo lines for itself.
+__device__ __forceinline__ unsigned strip4_patch(int remap) {
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (remap && gridDim.z == 1) {
+        const int G = gridDim.x * gridDim.y;
+        const int p = xcd_remap((int)(by * gridDim.x + bx), G);
+        by = p / gridDim.x;
+        bx = p - by * gridDim.x;
+    }
+    return bx | (by << 16);
+}
+
+__device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned pxy) {
     Strip4Node g;
     const int T = T4_L - 2 * H;          // halo depth is a launch parameter (8..10): K <= H sweeps per launch
     const int lx = threadIdx.x & 63, ly = 4 * (threadIdx.x >> 6) + r;
-    const int x0 = blockIdx.x * T - H, y0 = blockIdx.y * T - H;
+    const int x0 = (int)(pxy & 0xffffu) * T - H, y0 = (int)(pxy >> 16) * T - H;
     const int gx = x0 + lx, gy = y0 + ly;
     g.inside = gx >= 0 && gx < N && gy >= 0 && gy < N;
     g.i = g.inside ? gy * N + gx : 0;
@@ -1483,7 +1497,7 @@ __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                 double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
                 int g_build, double rel_tol, double* __restrict__ bigpart, int H, int check_every, int stagger,
-                const unsigned long long* __restrict__ lmask) {
+                const unsigned long long* __restrict__ lmask, int remap) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     __shared__ double smem[32];
@@ -1531,8 +1545,9 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     const double* zero = reinterpret_cast<const double*>(lmask) - 1;   // the word in front of the masks holds 0
     const int64_t zoff = zero - L;                                     // (flat global address space)
     unsigned nzbits[4];
+    const unsigned pxy = strip4_patch(remap);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { g[r] = strip4_node(N, r, H); nzbits[r] = 0x3fu; }
+    for (int r = 0; r < 4; ++r) { g[r] = strip4_node(N, r, H, pxy); nzbits[r] = 0x3fu; }
     if (lmask) {
         unsigned long long mw[4][W - 1];
 #pragma unroll
@@ -1623,7 +1638,7 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restrict__ b_, const double* __restrict__ ymid_,
               const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
-              CheOmegas om, double md_scale, ChebIO cio, int H) {
+              CheOmegas om, double md_scale, ChebIO cio, int H, int remap) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     if (cio.mat) M = cio.mat + (int64_t)blockIdx.z * cio.mat_bs;
@@ -1640,7 +1655,7 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
     double mv[4][W - 1], bv[4], ym[4], yo[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        g[r] = strip4_node(N, r, H);
+        g[r] = strip4_node(N, r, H, strip4_patch(remap));
         bv[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0;
 #pragma unroll
         for (int s = 0; s < W - 1; ++s) mv[r][s] = 0.0;
@@ -1690,7 +1705,7 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const double* __restrict__ ymid_,
                    const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
-                   CheOmegas om, double md_scale, int H) {
+                   CheOmegas om, double md_scale, int H, int remap) {
     __shared__ double top[2][16][64], bot[2][16][64];
     const int64_t voff = (int64_t)blockIdx.z * n;
     const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
@@ -1701,7 +1716,7 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
     int pc[4];            // six 2-bit edge counts, slots E, NE, N, W, SW, S
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        g[r] = strip4_node(N, r, H);
+        g[r] = strip4_node(N, r, H, strip4_patch(remap));
         bv[r] = 0.0; cw[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0; pc[r] = 0;
         if (g[r].inside) {
             const int gy = g[r].i / N, gx = g[r].i - gy * N;
@@ -1813,16 +1828,16 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     if (ctx->t4_dpp) {
         if (big) {
             hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every, (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every, (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask, ctx->t4_xcd);
             hipLaunchKernelGGL(k_reduce_resid, dim3(batch), dim3(STRIP_T), 0, ctx->stream, ctx->d_bigpart, (int64_t)t * t,
                                ctx->d_ctl, launch);
         } else if (check_every > 0) {
             hipLaunchKernelGGL(k_strip4_jacobi<2>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
-                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every, 0, lmask);
+                               ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, check_every, 0, lmask, 0);
         } else {
             hipLaunchKernelGGL(k_strip4_jacobi<0>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
                                ctx->d_ctl, launch, K, g_build, ctx->rel_tol, (double*)nullptr, H, 0,
-                               (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask);
+                               (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask, ctx->t4_xcd);
         }
     } else if (big) {
         hipLaunchKernelGGL(k_tile4_jacobi<1>, grid, dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
@@ -1865,10 +1880,10 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         femfct_prof_begin(ctx, KC_CHEB);
         if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in)
             hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
-                               mid, old, omid, oold, k1 - k0, om, md_scale, H);
+                               mid, old, omid, oold, k1 - k0, om, md_scale, H, ctx->t4_xcd);
         else if (ctx->t4_dpp)
             hipLaunchKernelGGL(k_strip4_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
-                               old, omid, oold, k1 - k0, om, md_scale, io, H);
+                               old, omid, oold, k1 - k0, om, md_scale, io, H, ctx->t4_xcd);
         else
             hipLaunchKernelGGL(k_tile4_cheb, dim3(t, t, batch), dim3(STRIP_T), lds, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
                                old, omid, oold, k1 - k0, om, md_scale, io);

@@ -21,6 +21,44 @@ __global__ void k_ell_transpose(int n, int W, const int32_t* __restrict__ cols, 
     }
 }
 
+// out = alpha*a + (beta * scale[*level + off]) * b: an operator whose convection part carries a time-dependent scalar
+// factor (separable wind w(x, t) = s(t) w0(x): A(t_n) = s(t_n) * A0), refreshed per step inside the captured graph
+__global__ void k_axpby_level(int64_t count, double alpha, const double* __restrict__ a, double beta,
+                              const double* __restrict__ b, const double* __restrict__ scale,
+                              const int32_t* __restrict__ level, int off, double* __restrict__ out) {
+    const double bs = beta * scale[*level + off];
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < count; k += stride) out[k] = alpha * a[k] + bs * b[k];
+}
+
+int enqueue_axpby_level(femfct_ctx* ctx, int64_t count, double alpha, const double* a, double beta, const double* b,
+                        const double* scale, int off, double* out) {
+    int64_t g = (count + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_axpby_level, dim3((unsigned)g), dim3(256), 0, ctx->stream, count, alpha, a, beta, b, scale,
+                       ctx->d_level, off, out);
+    return FEMFCT_OK;
+}
+
+// per-level wind factors s(t_0..t_Nt) of a sweep, uploaded into the ctx-owned buffer (null: stationary wind)
+int upload_wind_scale(femfct_ctx* ctx, const double* scale_host, int32_t num_steps, const double** dev) {
+    *dev = nullptr;
+    if (!scale_host) return FEMFCT_OK;
+    const size_t cnt = (size_t)num_steps + 1;
+    if (cnt > ctx->wscale_count) {
+        femfct_drop_graphs(ctx);
+        if (ctx->d_wscale) hipFree(ctx->d_wscale);
+        ctx->d_wscale = nullptr; ctx->wscale_count = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wscale, sizeof(double) * cnt));
+        ctx->wscale_count = cnt;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wscale, scale_host, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // scale_host may be a temporary of the caller
+    *dev = ctx->d_wscale;
+    return FEMFCT_OK;
+}
+
 struct Lv {  // VecRef factory bound to the ctx level counter
     const int32_t* lv;
     int64_t n;
@@ -200,6 +238,16 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
 int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c_level, double* u_traj,
                           double* v_traj, int32_t num_steps, double dt, const double* par, double rescaling,
                           int32_t batch) {
+    return femfct_schnak_forward_tw(ctx, Aw_ell, nullptr, c_level, u_traj, v_traj, num_steps, dt, par, rescaling, batch);
+}
+
+// The same with a separable time-dependent wind w(x, t) = s(t) w0(x) (Schnak_FCT_PDECO_alltime.py:55,174-175:
+// sin(2 pi t) * rotation, re-assembled every step; helpers.py:566 sets wind.t = t_{n+1} before assembling):
+// Aw_ell = assemble(dot(w0, grad(v))*u*dx), wind_scale_host[k] = s(t_k), k = 0..num_steps; the step to level n+1
+// uses s(t_{n+1}).  NULL: stationary wind.
+int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double* wind_scale_host, const double* c_level,
+                             double* u_traj, double* v_traj, int32_t num_steps, double dt, const double* par,
+                             double rescaling, int32_t batch) {
     FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
@@ -209,23 +257,34 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
     const double Du = par[0], Dv = par[1], c_b = par[2], gam = par[3], om1 = par[4], om2 = par[5];
     const int64_t n = ctx->n, wn = (int64_t)ctx->W * n, ts = (int64_t)(num_steps + 1) * n;
     Lv L{ctx->d_level, n};
-    auto begin = [&]() {
-        // Mat_var1 = Du*Ad - omega1*A (helpers.py:583); non_flux_mat = gamma*M (:588, shared)
-        for (int32_t b = 0; b < batch; ++b) femfct_enqueue_axpby(ctx, wn, Du, ctx->d_Ad, -om1, Aw_ell, ctx->d_trA + b * wn);
-        femfct_enqueue_axpby(ctx, wn, gam, ctx->d_M, 0.0, nullptr, ctx->d_trN);
-        // Base2 = M + dt*(Dv*Ad - omega2*A)  (helpers.py:595 without the u-dependent part)
-        femfct_enqueue_axpby(ctx, wn, Dv, ctx->d_Ad, -om2, Aw_ell, ctx->d_trBase2);
+    const double* wsc = nullptr;
+    if ((rc = upload_wind_scale(ctx, wind_scale_host, num_steps, &wsc)) != FEMFCT_OK) return rc;
+    // the wind-dependent operators: once per sweep for a stationary wind, once per step (level + lvoff) otherwise
+    auto wind_ops = [&](int lvoff) {
+        // Mat_var1 = Du*Ad - omega1*A (helpers.py:583)
+        for (int32_t b = 0; b < batch; ++b) {
+            if (wsc) enqueue_axpby_level(ctx, wn, Du, ctx->d_Ad, -om1, Aw_ell, wsc, lvoff, ctx->d_trA + b * wn);
+            else femfct_enqueue_axpby(ctx, wn, Du, ctx->d_Ad, -om1, Aw_ell, ctx->d_trA + b * wn);
+        }
+        // Base = M + dt*(Dv*Ad - omega2*A)  (helpers.py:595 without the u-dependent part)
+        if (wsc) enqueue_axpby_level(ctx, wn, Dv, ctx->d_Ad, -om2, Aw_ell, wsc, lvoff, ctx->d_trBase2);
+        else femfct_enqueue_axpby(ctx, wn, Dv, ctx->d_Ad, -om2, Aw_ell, ctx->d_trBase2);
         WMassSpec ws;
         ws.alpha = 1.0; ws.gamma = dt; ws.base = ctx->d_trBase2;
         return femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
+    };
+    auto begin = [&]() {
+        femfct_enqueue_axpby(ctx, wn, gam, ctx->d_M, 0.0, nullptr, ctx->d_trN);   // non_flux_mat = gamma*M (:588, shared)
+        return wsc ? (int)FEMFCT_OK : wind_ops(0);
     };
     auto step = [&](int budget, int kbudget, int reps) {
         auto key = KEY((uint64_t)12, key_bits(Aw_ell), key_bits(c_level), key_bits(u_traj), key_bits(v_traj),
                        key_bits(num_steps), key_bits(dt), key_bits(Du), key_bits(Dv), key_bits(c_b), key_bits(gam),
                        key_bits(om1), key_bits(om2), key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget),
                        key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
-                       key_bits((int32_t)femfct_species_cheb(ctx, 12)));
+                       key_bits((int32_t)femfct_species_cheb(ctx, 12)), key_bits(wsc));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
+            if (wsc) wind_ops(1);       // wind.t = t_{n+1} (helpers.py:565-566)
             LoadSpec l1;  // (gamma/r*c + gamma*u_n^2*v_n)*v*dx  (helpers.py:584-585)
             l1.s1 = 1.0; l1.k1 = gam / rescaling; l1.p1 = make_ref(c_level); l1.p1_bs = n;
             l1.k2 = gam; l1.q1 = L(u_traj, 0); l1.q2 = L(u_traj, 0); l1.q3 = L(v_traj, 0);
@@ -256,6 +315,16 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
 int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* u_traj, const double* v_traj,
                           const double* uhat_T, const double* vhat_T, double* p_traj, double* q_traj,
                           int32_t num_steps, double dt, const double* par, int32_t alltime, int32_t batch) {
+    return femfct_schnak_adjoint_tw(ctx, AwT_ell, nullptr, u_traj, v_traj, uhat_T, vhat_T, p_traj, q_traj, num_steps, dt, par,
+                                    alltime, batch);
+}
+
+// with the separable time-dependent wind of femfct_schnak_forward_tw: the step that produces level n uses s(t_n)
+// (helpers.py:664-679: t -= dt; wind.t = t)
+int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const double* wind_scale_host, const double* u_traj,
+                             const double* v_traj, const double* uhat_T, const double* vhat_T, double* p_traj,
+                             double* q_traj, int32_t num_steps, double dt, const double* par, int32_t alltime,
+                             int32_t batch) {
     FEMFCT_ENTER(ctx);
     int rc = check_common(ctx, num_steps, dt, batch);
     if (rc != FEMFCT_OK) return rc;
@@ -265,12 +334,21 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
     const double Du = par[0], Dv = par[1], gam = par[3], om1 = par[4], om2 = par[5];
     const int64_t n = ctx->n, wn = (int64_t)ctx->W * n, ts = (int64_t)(num_steps + 1) * n;
     Lv L{ctx->d_level, n};
-    auto begin = [&]() {
-        for (int32_t b = 0; b < batch; ++b) femfct_enqueue_axpby(ctx, wn, Du, ctx->d_Ad, -om1, AwT_ell, ctx->d_trA + b * wn);
-        femfct_enqueue_axpby(ctx, wn, Dv, ctx->d_Ad, -om2, AwT_ell, ctx->d_trBase2);
+    const double* wsc = nullptr;
+    if ((rc = upload_wind_scale(ctx, wind_scale_host, num_steps, &wsc)) != FEMFCT_OK) return rc;
+    auto wind_ops = [&](int lvoff) {
+        for (int32_t b = 0; b < batch; ++b) {
+            if (wsc) enqueue_axpby_level(ctx, wn, Du, ctx->d_Ad, -om1, AwT_ell, wsc, lvoff, ctx->d_trA + b * wn);
+            else femfct_enqueue_axpby(ctx, wn, Du, ctx->d_Ad, -om1, AwT_ell, ctx->d_trA + b * wn);
+        }
+        if (wsc) enqueue_axpby_level(ctx, wn, Dv, ctx->d_Ad, -om2, AwT_ell, wsc, lvoff, ctx->d_trBase2);
+        else femfct_enqueue_axpby(ctx, wn, Dv, ctx->d_Ad, -om2, AwT_ell, ctx->d_trBase2);
         WMassSpec ws;
         ws.alpha = 1.0; ws.gamma = dt; ws.base = ctx->d_trBase2;
-        femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
+        return femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
+    };
+    auto begin = [&]() {
+        if (!wsc) wind_ops(0);
         if (alltime) {
             for (int32_t b = 0; b < batch; ++b) {
                 HIP_TRY(ctx, hipMemsetAsync(p_traj + b * ts + (int64_t)num_steps * n, 0, sizeof(double) * n, ctx->stream));
@@ -286,8 +364,9 @@ int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* 
                        key_bits(vhat_T), key_bits(p_traj), key_bits(q_traj), key_bits(num_steps), key_bits(dt),
                        key_bits(Du), key_bits(Dv), key_bits(gam), key_bits(om1), key_bits(om2), key_bits(batch),
                        key_bits(alltime), key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
-                       key_bits((int32_t)femfct_species_cheb(ctx, 13)));
+                       key_bits((int32_t)femfct_species_cheb(ctx, 13)), key_bits(wsc));
         return femfct_run_graph_reps(ctx, key, reps, [&]() {
+            if (wsc) wind_ops(0);       // level counter = n: wind.t = t_n (helpers.py:664,679)
             // q first (helpers.py:683-686): Mat_q = M + dt*(Dv*Ad - omega2*A' + gamma*M_u2(u_n))
             WMassSpec wq;
             wq.gamma = 1.0; wq.base = ctx->d_trBase; wq.beta = dt * gam;

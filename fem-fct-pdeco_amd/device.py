@@ -69,6 +69,13 @@ class DeviceArray:
             self.ctx._arrays.discard(self)
 
 
+def _wind_scale(wind_scale, num_steps) -> np.ndarray:
+    ws = _as_f64(wind_scale).reshape(-1)
+    if ws.size != num_steps + 1:
+        raise ValueError(f"wind_scale: {ws.size} values, expected num_steps + 1 = {num_steps + 1} (s(t_0) .. s(t_Nt))")
+    return ws
+
+
 def dptr(x) -> int:
     """device address of a DeviceArray / torch tensor / raw int (None -> 0)."""
     if x is None:
@@ -353,16 +360,21 @@ class Context:
         check(self.handle, lib.femfct_nonlinear_adjoint(self.handle, dptr(Aw), dptr(u), dptr(uhat_T), dptr(p),
                                                         int(num_steps), float(dt), float(eps), int(batch)))
 
-    def schnak_forward(self, Aw, c_level, u, v, num_steps, dt, par, rescaling=1.0, batch=1):
+    def schnak_forward(self, Aw, c_level, u, v, num_steps, dt, par, rescaling=1.0, batch=1, wind_scale=None):
+        """wind_scale: None (stationary wind) or the num_steps+1 factors s(t_k) of a separable wind s(t) w0(x)."""
         par = _as_f64(par)
-        check(self.handle, lib.femfct_schnak_forward(self.handle, dptr(Aw), dptr(c_level), dptr(u), dptr(v),
-                                                     int(num_steps), float(dt), _host_ptr(par), float(rescaling), int(batch)))
+        ws = None if wind_scale is None else _wind_scale(wind_scale, num_steps)
+        check(self.handle, lib.femfct_schnak_forward_tw(self.handle, dptr(Aw), None if ws is None else _host_ptr(ws),
+                                                        dptr(c_level), dptr(u), dptr(v), int(num_steps), float(dt),
+                                                        _host_ptr(par), float(rescaling), int(batch)))
 
-    def schnak_adjoint(self, AwT, u, v, uhat_T, vhat_T, p, q, num_steps, dt, par, batch=1, alltime=False):
+    def schnak_adjoint(self, AwT, u, v, uhat_T, vhat_T, p, q, num_steps, dt, par, batch=1, alltime=False, wind_scale=None):
         par = _as_f64(par)
-        check(self.handle, lib.femfct_schnak_adjoint(self.handle, dptr(AwT), dptr(u), dptr(v), dptr(uhat_T), dptr(vhat_T),
-                                                     dptr(p), dptr(q), int(num_steps), float(dt), _host_ptr(par),
-                                                     int(bool(alltime)), int(batch)))
+        ws = None if wind_scale is None else _wind_scale(wind_scale, num_steps)
+        check(self.handle, lib.femfct_schnak_adjoint_tw(self.handle, dptr(AwT), None if ws is None else _host_ptr(ws),
+                                                        dptr(u), dptr(v), dptr(uhat_T), dptr(vhat_T), dptr(p), dptr(q),
+                                                        int(num_steps), float(dt), _host_ptr(par), int(bool(alltime)),
+                                                        int(batch)))
 
     def chtxs_forward(self, c_level, u, v, num_steps, dt, par, rescaling=0.1, batch=1):
         par = _as_f64(par)

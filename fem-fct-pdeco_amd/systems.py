@@ -95,7 +95,7 @@ class PDESystems:
 
     def convection(self, wind, name=None):
         """assemble_sparse(dot(wind, grad(v))*u*dx) on the device (cached per wind)."""
-        key = name or id(wind)
+        key = name if name is not None else wind       # the function object itself: stays alive, never aliases
         if key not in self._conv:
             xq, yq = self.ctx.quad_points(self.mesh.n_cells)
             wx, wy = wind(xq, yq)
@@ -203,18 +203,37 @@ def _schnak_par():
     return [Du, Dv, c_b, gamma, omega1, omega2], wind
 
 
+def _wind_factors(wind_scale, num_steps, dt, t0=0.0):
+    """s(t_k), k = 0..num_steps, from a callable ``s(t)`` or an array; None stays None (stationary wind)."""
+    if wind_scale is None:
+        return None
+    if callable(wind_scale):
+        return np.array([float(wind_scale(t0 + k * dt)) for k in range(num_steps + 1)])
+    ws = np.asarray(wind_scale, dtype=np.float64).ravel()
+    if ws.size != num_steps + 1:
+        raise ValueError(f"wind_scale: {ws.size} values, expected num_steps + 1 = {num_steps + 1}")
+    return ws
+
+
 def solve_schnak_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighbors,
-                        control_fun=None, rescaling=1):
-    """helpers.py:511-597: mutates and returns ``(var1, var2)``."""
+                        control_fun=None, rescaling=1, wind=None, wind_scale=None):
+    """helpers.py:511-597: mutates and returns ``(var1, var2)``.
+
+    Extension for the script BASELINE config 3 names (Schnak_FCT_PDECO_alltime.py:55,174-175: the wind
+    ``(-(y-.5), (x-.5)) * sin(2 pi t)``, re-assembled per step): ``wind=w0`` (a function ``(x, y) -> (wx, wy)``,
+    default the stationary wind of helpers.py:506-508) and ``wind_scale=s`` (callable ``s(t)`` or the array
+    ``s(t_0..t_Nt)``) give the separable wind ``s(t) w0(x)``; the step to level n+1 uses ``s(t_{n+1})``
+    (helpers.py:565-566: ``t += dt; wind.t = t``)."""
     S = _system(V)
-    par, wind = _schnak_par()
-    Aw, _ = S.convection(wind, "schnak")
+    par, wind0 = _schnak_par()
+    Aw, _ = S.convection(wind or wind0, None if wind is not None else "schnak")
     var1[nodes:] = np.zeros(num_steps * nodes)
     var2[nodes:] = np.zeros(num_steps * nodes)
     B = _Bufs(S)
     try:
         u, v = B.up(var1), B.up(var2)
-        S.ctx.schnak_forward(Aw, B.up(_frozen_control(control, control_fun, nodes)), u, v, num_steps, dt, par, rescaling)
+        S.ctx.schnak_forward(Aw, B.up(_frozen_control(control, control_fun, nodes)), u, v, num_steps, dt, par, rescaling,
+                             wind_scale=_wind_factors(wind_scale, num_steps, dt))
         B.down(u, var1)
         B.down(v, var2)
     finally:
@@ -223,20 +242,22 @@ def solve_schnak_system(control, var1, var2, V, nodes, num_steps, dt, dof_neighb
 
 
 def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, V, nodes, num_steps, dt, dof_neighbors,
-                                optim="finaltime"):
+                                optim="finaltime", wind=None, wind_scale=None):
     """helpers.py:599-698 (``optim="finaltime"``, the reference's signature and behaviour).
     ``optim="alltime"`` (extension, structure of Schnak_FCT_PDECO_alltime.py:204-284): the targets are
-    trajectories, p(T) = q(T) = 0 and both equations carry the assembled misfit."""
+    trajectories, p(T) = q(T) = 0 and both equations carry the assembled misfit.
+    ``wind`` / ``wind_scale``: as in :func:`solve_schnak_system`; the step that produces level n uses ``s(t_n)``
+    (helpers.py:664, 679: ``t -= dt; wind.t = t``)."""
     if optim not in ("alltime", "finaltime"):
         raise ValueError(f"Invalid value for 'optim': '{optim}'. Must be one of ['alltime', 'finaltime'].")
     S = _system(V)
-    par, wind = _schnak_par()
-    _, AwT = S.convection(wind, "schnak")
+    par, wind0 = _schnak_par()
+    _, AwT = S.convection(wind or wind0, None if wind is not None else "schnak")
     B = _Bufs(S)
     try:
         p, q = B.up(pk), B.up(qk)
         S.ctx.schnak_adjoint(AwT, B.up(uk), B.up(vk), B.up(uhat_T), B.up(vhat_T), p, q, num_steps, dt, par,
-                             alltime=optim == "alltime")
+                             alltime=optim == "alltime", wind_scale=_wind_factors(wind_scale, num_steps, dt))
         B.down(p, pk)
         B.down(q, qk)
     finally:

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FEMFCT_ABI_VERSION 3   /* 3: femfct_kernel_regime, femfct_chebsi_md; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
+#define FEMFCT_ABI_VERSION 3   /* 3: femfct_kernel_regime, femfct_chebsi_md, femfct_schnak_*_tw; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
 
 typedef struct femfct_ctx femfct_ctx;
 
@@ -278,6 +278,18 @@ int femfct_schnak_forward(femfct_ctx* ctx, const double* Aw_ell, const double* c
 int femfct_schnak_adjoint(femfct_ctx* ctx, const double* AwT_ell, const double* u_traj, const double* v_traj,
                           const double* uhat_T, const double* vhat_T, double* p_traj, double* q_traj,
                           int32_t num_steps, double dt, const double* par, int32_t alltime, int32_t batch);
+/* The two Schnakenberg sweeps with a separable time-dependent wind w(x, t) = s(t) w0(x) -- the set-up of the script
+ * BASELINE config 3 names, Schnak_FCT_PDECO_alltime.py:55,174-175,228-230 (rotation * sin(2 pi t), convection matrix
+ * re-assembled every step; helpers.py:565-566, 664, 679 set wind.t the same way).  Aw_ell / AwT_ell are the matrices
+ * of w0; wind_scale_host[k] = s(t_k), k = 0..num_steps (host array, copied).  The step to level n+1 (forward) uses
+ * s(t_{n+1}); the step to level n (adjoint) uses s(t_n).  wind_scale_host == NULL: stationary wind (= the calls above). */
+int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double* wind_scale_host, const double* c_level,
+                             double* u_traj, double* v_traj, int32_t num_steps, double dt, const double* par,
+                             double rescaling, int32_t batch);
+int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const double* wind_scale_host, const double* u_traj,
+                             const double* v_traj, const double* uhat_T, const double* vhat_T, double* p_traj,
+                             double* q_traj, int32_t num_steps, double dt, const double* par, int32_t alltime,
+                             int32_t batch);
 /* solve_chtxs_system (helpers.py:1250-1385, non-generation mode); par = {delta, Dm, Df, chi, eta} */
 int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj, double* v_traj,
                          int32_t num_steps, double dt, const double* par, double rescaling, int32_t batch);

@@ -140,18 +140,23 @@ def solve_adjoint_nonlinear_equation(uk, uhat_T, pk, T, asm, nodes, num_steps, d
 # advective Schnakenberg
 # ---------------------------------------------------------------------------
 def solve_schnak_system(control, var1, var2, asm, nodes, num_steps, dt, dof_neighbors=None,
-                        control_const=None, rescaling=1):
-    """helpers.py:511-597."""
+                        control_const=None, rescaling=1, wind=None, wind_scale=None):
+    """helpers.py:511-597.  wind / wind_scale: the separable time-dependent wind s(t) w0(x) of
+    Schnak_FCT_PDECO_alltime.py:55,174-175 -- ``wind.t = t`` with t = t_{n+1} before the matrix is assembled
+    (helpers.py:565-566); for the stationary HEAD wind the assignment has no effect."""
     cm = _common(asm)
     P = schnak_params()
     Du, Dv, c_b, gamma, om1, om2 = P["Du"], P["Dv"], P["c_b"], P["gamma"], P["omega1"], P["omega2"]
     var1[nodes:] = np.zeros(num_steps * nodes)
     var2[nodes:] = np.zeros(num_steps * nodes)
-    A = asm.convection(schnak_wind)  # wind.t has no effect (helpers.py:506-508)
+    A0 = asm.convection(wind or schnak_wind)  # wind.t has no effect on the HEAD wind (helpers.py:506-508)
     rhs_var2 = asm.load(lambda at: np.full_like(at(np.zeros(nodes)), gamma * c_b))
     frozen = None
+    t = 0.0
     for i in range(1, num_steps + 1):
         start, end = i * nodes, (i + 1) * nodes
+        t += dt
+        A = A0 if wind_scale is None else float(wind_scale(t)) * A0      # assemble(dot(s(t) w0, grad(v))*u*dx)
         u_n = var1[start - nodes:start]
         v_n = var2[start - nodes:start]
         if frozen is None:  # quirk 1
@@ -168,7 +173,7 @@ def solve_schnak_system(control, var1, var2, asm, nodes, num_steps, dt, dof_neig
 
 
 def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, asm, nodes, num_steps, dt,
-                                dof_neighbors=None, optim="finaltime"):
+                                dof_neighbors=None, optim="finaltime", wind=None, wind_scale=None):
     """helpers.py:599-698 (optim="finaltime").  optim="alltime" is an extension without a HEAD counterpart:
     zero terminal conditions and the misfit loads of the inline loop Schnak_FCT_PDECO_alltime.py:268
     (rhs_q += assemble((vhat_n - v_n)*w*dx)) and :278 (rhs_p += assemble((uhat_n - u_n)*w*dx)), alpha = 1."""
@@ -183,9 +188,12 @@ def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, asm, nodes, n
         pk[num_steps * nodes:] = uhat_T - uk[num_steps * nodes:]
         qk[num_steps * nodes:] = vhat_T - vk[num_steps * nodes:]
     # dot(wind, grad(u))*w*dx is the transpose of dot(wind, grad(w))*u*dx (helpers.py:681)
-    A = asm.convection(schnak_wind).T.tocsr()
+    A0 = asm.convection(wind or schnak_wind).T.tocsr()
+    t = T
     for i in reversed(range(0, num_steps)):
         start, end = i * nodes, (i + 1) * nodes
+        t -= dt                                                            # helpers.py:664, 679: wind.t = t_n
+        A = A0 if wind_scale is None else float(wind_scale(t)) * A0
         q_np1 = qk[end:end + nodes]
         p_np1 = pk[end:end + nodes]
         u_n = uk[start:end]

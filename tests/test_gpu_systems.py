@@ -322,3 +322,43 @@ def test_species_solver_falls_back_to_bicgstab_when_chebyshev_runs_out_of_iterat
             ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0)
     finally:
         S.close()
+
+
+def test_schnak_time_dependent_wind_of_the_named_config3_script(hp):
+    """Schnak_FCT_PDECO_alltime.py:55,174-175,228-230 (the script BASELINE config 3 names): the wind is
+    (-(y-.5), (x-.5)) * sin(2 pi t), re-assembled every step.  Separable => A(t_n) = sin(2 pi t_n) * A0 with a
+    per-level factor refreshed inside the captured graph.  Forward + final-time and all-time adjoints against the
+    oracle at the script's dt = 2e-3 on a 13 x 13 mesh; a factor of one reproduces the stationary sweep bit for bit."""
+    from oracle import traj as otraj
+    mesh, asm = _oracle(0.0, 1.0, 12)
+    V = hp.SquareMeshP1(0.0, 1.0, 12)
+    n, Nt, dt = V.nodes, 12, 2e-3
+    rot = lambda x, y: (-(y - 0.5), (x - 0.5))
+    s_t = lambda t: np.sin(2 * np.pi * 40 * t)          # 40x faster than the script's so that 12 steps see a sign change
+    rng = np.random.default_rng(6)
+    u0, v0 = hp.schnak_sys_IC(0, 1, 1 / 12, n, V.vertex_to_dof)
+    ctrl = 0.1 + 0.05 * rng.random((Nt + 1) * n)
+    z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
+    uo, vo = otraj.solve_schnak_system(ctrl, z(u0), z(v0), asm, n, Nt, dt, wind=rot, wind_scale=s_t)
+    ug, vg = hp.solve_schnak_system(ctrl, z(u0), z(v0), V, n, Nt, dt, None, wind=rot, wind_scale=s_t)
+    assert rel(ug, uo) < 1e-9 and rel(vg, vo) < 1e-9
+    # it is not the stationary problem
+    us, _ = hp.solve_schnak_system(ctrl, z(u0), z(v0), V, n, Nt, dt, None, wind=rot)
+    assert rel(us, ug) > 1e-4
+    zz = lambda: np.zeros_like(uo)
+    uhat, vhat = 0.9 * uo[Nt * n:], 1.1 * vo[Nt * n:]
+    po, qo = otraj.solve_adjoint_schnak_system(uo, vo, uhat, vhat, zz(), zz(), Nt * dt, asm, n, Nt, dt, wind=rot, wind_scale=s_t)
+    pg, qg = hp.solve_adjoint_schnak_system(ug, vg, uhat, vhat, zz(), zz(), Nt * dt, V, n, Nt, dt, None, wind=rot, wind_scale=s_t)
+    assert rel(pg, po) < 1e-8 and rel(qg, qo) < 1e-8
+    uh, vh = 0.9 * uo + 0.01, 1.1 * vo
+    po, qo = otraj.solve_adjoint_schnak_system(uo, vo, uh, vh, zz(), zz(), Nt * dt, asm, n, Nt, dt, None, "alltime",
+                                               wind=rot, wind_scale=s_t)
+    pg, qg = hp.solve_adjoint_schnak_system(ug, vg, uh, vh, zz(), zz(), Nt * dt, V, n, Nt, dt, None, optim="alltime",
+                                            wind=rot, wind_scale=s_t)
+    assert rel(pg, po) < 1e-8 and rel(qg, qo) < 1e-8
+    # factor one == the stationary path, bitwise
+    u1, v1 = hp.solve_schnak_system(ctrl, z(u0), z(v0), V, n, Nt, dt, None, wind=rot, wind_scale=np.ones(Nt + 1))
+    us, vs = hp.solve_schnak_system(ctrl, z(u0), z(v0), V, n, Nt, dt, None, wind=rot)
+    assert np.array_equal(u1, us) and np.array_equal(v1, vs)
+    with pytest.raises(ValueError):
+        hp.solve_schnak_system(ctrl, z(u0), z(v0), V, n, Nt, dt, None, wind=rot, wind_scale=np.ones(Nt))

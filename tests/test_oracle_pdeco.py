@@ -39,3 +39,27 @@ def test_failed_line_searches_end_the_loop_and_restore_the_control():
     assert r["armijo_its"] == [1, 1]            # the third failure breaks before the metrics are appended
     assert r["restored"] and r["it"] == 2 and r["it_backup"] == 0
     assert len(r["cost"]) == 3
+
+
+def test_oracle_schnak_time_dependent_wind_reduces_to_stationary():
+    """oracle.traj: the separable wind s(t) w0(x) (Schnak_FCT_PDECO_alltime.py:55,174-175) with s == 1 is the HEAD
+    solver; with s == 0 the convection drops out of both species (pure reaction-diffusion: the wind cannot matter)."""
+    import numpy as np
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    from oracle import traj as otraj
+    asm = P1Assembler(SquareMesh(0, 1, 8))
+    n, Nt, dt = asm.n, 4, 1e-3
+    rng = np.random.default_rng(0)
+    z = lambda: np.concatenate([1.0 + 0.1 * rng.random(n), np.zeros(Nt * n)])
+    u0, v0 = z(), z()
+    c = 0.1 * np.ones((Nt + 1) * n)
+    a = otraj.solve_schnak_system(c, u0.copy(), v0.copy(), asm, n, Nt, dt)
+    b = otraj.solve_schnak_system(c, u0.copy(), v0.copy(), asm, n, Nt, dt, wind=otraj.schnak_wind, wind_scale=lambda t: 1.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    w1 = lambda x, y: (-(y - 0.5), (x - 0.5))
+    w2 = lambda x, y: (x, 2 * y)
+    p = otraj.solve_schnak_system(c, u0.copy(), v0.copy(), asm, n, Nt, dt, wind=w1, wind_scale=lambda t: 0.0)
+    q = otraj.solve_schnak_system(c, u0.copy(), v0.copy(), asm, n, Nt, dt, wind=w2, wind_scale=lambda t: 0.0)
+    assert np.allclose(p[0], q[0], rtol=0, atol=1e-14) and np.allclose(p[1], q[1], rtol=0, atol=1e-14)
+    assert np.abs(a[0] - p[0]).max() > 1e-6
