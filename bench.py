@@ -450,7 +450,7 @@ def roofline(hp, solvers, n_cells, steps, device_id):
 
     # PMC-derived HBM bytes per launch: only when measured on this very source tree (tools/refresh_profiles.sh)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    traffic, traffic_note = None, "profiles/traffic.json absent"
+    traffic, traffic1, traffic_note = None, None, "profiles/traffic.json absent"
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         ent = tj.get(f"n{n}")
@@ -461,6 +461,7 @@ def roofline(hp, solvers, n_cells, steps, device_id):
                             "omitted (re-run tools/refresh_profiles.sh)")
         else:
             traffic, traffic_note = ent["bytes_per_launch"], f"rocprofv3 PMC passes, source_sha16 {sha}"
+            traffic1 = ent.get("one_sweep_bytes_per_launch")
 
     # ---- (1) the product path at this size (fused multi-sweep kernels)
     step_ms, rep, sweeps = _profiled_forward(prob, ctx, d_c, d_u, steps)
@@ -511,6 +512,9 @@ def roofline(hp, solvers, n_cells, steps, device_id):
         by = bpr1[k] * n * ran
         k1[k] = {"launches": cnt, "executed": ran, "total_ms": ms, "compulsory_bytes_per_row_per_launch": bpr1[k],
                  "achieved_GBps": by / (1e6 * ms), "frac": by / (1e6 * ms) / HBM_PEAK_GBS}
+        if traffic1 and k in traffic1 and k != "assemble":
+            k1[k]["traffic_bytes_per_row"] = traffic1[k] / n
+            k1[k]["traffic_frac_incl_infinity_cache"] = traffic1[k] * ran / (1e6 * ms) / HBM_PEAK_GBS
     out["one_sweep_kernels"] = {"fct_step_ms": step1_ms, "fct_steps_per_s": 1e3 / step1_ms,
                                 "jacobi_sweeps_per_step": sweeps1 / steps, "kernels": k1,
                                 "note": "femfct_set_fusion(0, 0): k_jacobi / k_cheb (SpMV-type) and k_flux + k_limit, "

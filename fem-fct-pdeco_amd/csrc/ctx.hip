@@ -233,6 +233,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_LMASK")) ctx->l_mask = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_XCD")) ctx->t4_xcd = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_INLINE_OPS")) ctx->inline_ops = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_HALF_D")) ctx->half_d = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_STAGGER_US")) {
         const double us = atof(e);
         int pat = 7;

@@ -101,6 +101,7 @@ struct femfct_ctx {
     double* d_partk = nullptr;       // [B][16][MAX_PARTIALS] per-sweep residual partials of the last fused launch
     double* d_bigpart = nullptr;     // [B * bigpart_count] residual partials of fused launches on large grids
     unsigned long long* d_Lmask = nullptr;   // [B][6][ceil(n/64)] bit i of slot s: l_(i,s) != 0 (written by k_build_low for the 64-patch Jacobi kernels)
+    bool half_d = true;              // bandwidth regime: D stored once per edge (FEMFCT_HALF_D)
     bool inline_ops = true;          // solid-body sweeps in the bandwidth regime derive A inside the step kernels (FEMFCT_INLINE_OPS)
     bool l_mask = true;              // skip the exactly-zero off-diagonals of L when loading Jacobi patches (FEMFCT_LMASK)
     int64_t bigpart_count = 0;
@@ -221,7 +222,7 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
                              double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch,
                              const struct ChebIO* io = nullptr);
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
-                                   struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end);
+                                   struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end, int half_d = 0);
 int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, struct MatRef A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch, int* tail_first = nullptr);

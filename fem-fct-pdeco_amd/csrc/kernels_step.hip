@@ -109,7 +109,9 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
-                            unsigned long long* __restrict__ lmask) {
+                            unsigned long long* __restrict__ lmask, int half_d) {
+    // half_d: d_ij = d_ji to the bit (max is commutative), so only the three "forward" slots E, NE, N are stored;
+    // the limiter of the bandwidth regime (k_tile_flux_limit<.., HALFD = 1>) takes the other three from the neighbours
     __shared__ double smem[32];
     const int W = WT ? WT : Wrt;
     const int bz = blockIdx.y;
@@ -147,21 +149,24 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
             dsum += d;
             double l = dt * (a - d);
             if (Nm) l += dt * Nm[idx];
-            L[idx] = l;
-            D[idx] = d;
+            if (!half_d || s <= 3) D[idx] = d;
             rs += l;
             // which entries of this slot are exactly zero (the low-order operator is an upwind stencil: about half
-            // of its off-diagonals vanish): one bit per row, one 64-bit word per wave (row chunks are 64-aligned)
+            // of its off-diagonals vanish): one bit per row, one 64-bit word per wave (row chunks are 64-aligned).
+            // With the mask in force its only reader (k_strip4_jacobi) never touches a vanishing entry, so those are
+            // not stored either: a 128-byte line of zeros is neither written here nor read there.
             if (lmask) {
                 const unsigned long long nzb = __ballot(l != 0.0);
                 if ((threadIdx.x & 63) == 0) lmask[((int64_t)bz * nwords + (i >> 6)) * (W - 1) + (s - 1)] = nzb;   // [word][slot]
+                if (l != 0.0) L[idx] = l;
+            } else {
+                L[idx] = l;
             }
         }
         double mli = ml[i];
         double ld = mli + dt * (op.a(0, i) + dsum);                // d_ii = -sum_j d_ij
         if (Nm) ld += dt * Nm[i];
-        L[i] = ld;
-        D[i] = -dsum;
+        L[i] = ld;                  // (the diagonal of D is -dsum; the limiter reads off-diagonals only: not stored)
         rs += ld;
         double ui = u[i];
         double bi = mli * ui + (rhs ? dt * rhs[i] : 0.0);
@@ -187,9 +192,9 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
-                            unsigned long long* __restrict__ lmask) {
+                            unsigned long long* __restrict__ lmask, int half_d) {
     build_low_body<WT, BS, IMP>(n, Wrt, Nw, cols, tslot, MatOp{mat_ptr(A_ref, blockIdx.y), n}, N_, nshared, rhs_ref, u_ref,
-                                rhs_bstride, u_bstride, ml, dt, L_, D_, b_, x0_, part, ctl_, lmask);
+                                rhs_bstride, u_bstride, ml, dt, L_, D_, b_, x0_, part, ctl_, lmask, half_d);
 }
 
 // the same with the solid-body operator derived on the fly (structured mesh, vertex order)
@@ -199,11 +204,11 @@ __global__ void __launch_bounds__(BS) k_build_low_sb(int n, int Nw, double h, Sb
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
-                            unsigned long long* __restrict__ lmask) {
+                            unsigned long long* __restrict__ lmask, int half_d) {
     SbOp<true> op;
     op.p = sb; op.c = vec_ptr(sb.c) + blockIdx.y * sb.c_bstride; op.n = n; op.Nw = Nw; op.h = h;
     build_low_body<7, BS, 1>(n, 7, Nw, nullptr, nullptr, op, nullptr, 0, rhs_ref, u_ref, rhs_bstride, u_bstride, ml, dt,
-                             L_, D_, b_, x0_, part, ctl_, lmask);
+                             L_, D_, b_, x0_, part, ctl_, lmask, half_d);
 }
 
 // ---------------------------------------------------------------------------
@@ -638,16 +643,19 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
     // latency regime: the operator construction rides in the first tile-Jacobi launch
     const bool fused_build = ctx->fuse_build && tiles && !tile4 && !femfct_tile_big(ctx, tp) &&
                              ctx->solver != FEMFCT_SOLVER_BICGSTAB && (budget + tp.K - 1) / tp.K >= 2;
-    unsigned long long* lmask = (tile4 && ctx->l_mask && ctx->t4_dpp && W == 7) ? ctx->d_Lmask + 1 : nullptr;
+    unsigned long long* lmask = (tile4 && ctx->l_mask && ctx->t4_dpp && W == 7 && ctx->solver == FEMFCT_SOLVER_JACOBI)
+                                    ? ctx->d_Lmask + 1 : nullptr;
+    // symmetric storage of D between k_build_low and the 2-D tile limiter (both sides of this step or neither)
+    const int half_d = (tile4 && ctx->half_d && ctx->structured && ctx->implicit_cols && W == 7) ? 1 : 0;
     if (sb) {
         femfct_prof_begin(ctx, KC_BUILD_LOW);
         hipLaunchKernelGGL((k_build_low_sb<256>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, u_n, rhs_bstride,
-                           u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl, lmask);
+                           u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl, lmask, half_d);
         femfct_prof_end(ctx);
     } else if (!fused_build)
         LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n,
                  rhs_bstride, u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl,
-                 lmask);
+                 lmask, half_d);
     if (ctx->solver == FEMFCT_SOLVER_BICGSTAB) {
         // robust alternative for operators far from diagonal dominance: Jacobi-preconditioned BiCGStab
         // from x0 = u^n into d_xa; outcome mirrored into StepCtl (done, parity 0)
@@ -668,7 +676,7 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
         ipu = k4;
         for (int s = 0; s < units; ++s)
             femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch, h4, k4,
-                                        single ? 2 : 0, (ctx->l_mask && ctx->t4_dpp && W == 7) ? ctx->d_Lmask + 1 : nullptr);
+                                        single ? 2 : 0, lmask);
     } else if (tiles) {
         units = (budget + tp.K - 1) / tp.K;
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
@@ -730,7 +738,7 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
         // limiter already ran inside the fused tail
     } else if (tiles) {
         const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
-        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch, fuse_end);
+        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch, fuse_end, half_d);
         if (fuse_end) ctx->end_fused = true;
     } else {
         LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt,

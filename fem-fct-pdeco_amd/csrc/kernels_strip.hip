@@ -730,19 +730,30 @@ __device__ __forceinline__ int mass_edge_counts(int gx, int gy, int nc) {
 }
 
 #define FL_H 2
-template <int FL_L, int GEOM>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
-__global__ void __launch_bounds__(FL_L * FL_L)
+// (two 1024-thread workgroups per CU need <= 64 VGPRs: the second launch-bound argument is waves per SIMD)
+template <int FL_L, int GEOM, int HALFD>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
+__global__ void __launch_bounds__(FL_L * FL_L, FL_L == 32 ? 8 : 1)
 k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const double* __restrict__ D_,
                   const double* __restrict__ ulow_, const double* __restrict__ du_, const double* __restrict__ ml,
                   double dt, VecRef out_ref, int64_t out_bstride, EndArgs e) {
     constexpr int W = 7;
     constexpr int FL_LD = FL_L + 1, FL_T = FL_L - 2 * FL_H;
     __shared__ double su[FL_L * FL_LD], sd[FL_L * FL_LD], srp[FL_L * FL_LD], srm[FL_L * FL_LD];
+    __shared__ double sdf[HALFD ? 3 : 1][HALFD ? FL_L * FL_LD : 1];   // HALFD: the forward slots (E, NE, N) of D
     const int bz = blockIdx.z;
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const TileGeom g = tile_geom<FL_T, FL_H, FL_L>(N);
-    double ui = 0.0, dui = 0.0, mli = 1.0;
+    double ui = 0.0, dui = 0.0, mli = 1.0, dfw[3] = {0.0, 0.0, 0.0};
     if (g.inside) { ui = ulow_[voff + g.i]; dui = du_[voff + g.i]; mli = ml[g.i]; }
+    if (HALFD) {
+        // d_ij is stored once per edge, in the row whose slot towards the neighbour is E, NE or N (k_build_low, half_d)
+        if (g.inside) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) dfw[s] = D_[moff + (int64_t)(s + 1) * n + g.i];
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) sdf[s][g.self] = dfw[s];
+    }
     su[g.self] = ui;
     sd[g.self] = dui;
     srp[g.self] = 1.0;
@@ -753,13 +764,22 @@ k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const do
     const bool have = g.inside && g.kvalid >= 1;
     if (have) {
         double pp = 0.0, pm = 0.0, umax = ui, umin = ui;
-        const int pc = GEOM ? mass_edge_counts(g.gx, g.gy, N - 1) : 0;
+        const int pc = (GEOM || HALFD) ? mass_edge_counts(g.gx, g.gy, N - 1) : 0;
         const double mq = (0.5 * h * h) / 12.0;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             const int64_t idx = (int64_t)s * n + g.i;
             const double uj = su[g.nb[s - 1]];
-            const double mij = GEOM ? (double)((pc >> (2 * (s - 1))) & 3) * mq : M[idx], dij = D_[moff + idx];
+            const double mij = GEOM ? (double)((pc >> (2 * (s - 1))) & 3) * mq : M[idx];
+            double dij;
+            if (HALFD) {
+                // backward slots W, SW, S: the neighbour's forward entry (a neighbour outside the grid has none:
+                // its clamped LDS slot aliases a patch node)
+                const bool exists = ((pc >> (2 * (s - 1))) & 3) != 0;
+                dij = s <= 3 ? dfw[s - 1] : (exists ? sdf[s - 4][g.nb[s - 1]] : 0.0);
+            } else {
+                dij = D_[moff + idx];
+            }
             const double fs = mij * (dui - sd[g.nb[s - 1]]) + dij * (ui - uj);
             f[s - 1] = fs;
             pp += fmax(fs, 0.0);
@@ -937,7 +957,7 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
 }
 
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
-                                   VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end) {
+                                   VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end, int half_d) {
     EndArgs e;
     e.level = nullptr;
     if (fuse_end) {
@@ -947,14 +967,16 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
     }
     femfct_prof_begin(ctx, KC_FLUX);
     const bool geom = femfct_geom_mass(ctx);
-#define FL_(PL, G, T_) hipLaunchKernelGGL((k_tile_flux_limit<PL, G>), dim3(T_, T_, batch), dim3(PL * PL), 0, ctx->stream, ctx->n, \
-                                          ctx->N, ctx->h, ctx->d_M, D, ulow, du, ctx->d_ml, dt, out, out_bstride, e)
+#define FL_(PL, G, HD, T_) hipLaunchKernelGGL((k_tile_flux_limit<PL, G, HD>), dim3(T_, T_, batch), dim3(PL * PL), 0, ctx->stream, \
+                                              ctx->n, ctx->N, ctx->h, ctx->d_M, D, ulow, du, ctx->d_ml, dt, out, out_bstride, e)
     if (ctx->N <= 512) {
         const int t = (ctx->N + 11) / 12;
-        if (geom) FL_(16, 1, t); else FL_(16, 0, t);
+        if (half_d) { if (geom) FL_(16, 1, 1, t); else FL_(16, 0, 1, t); }
+        else { if (geom) FL_(16, 1, 0, t); else FL_(16, 0, 0, t); }
     } else {
         const int t = (ctx->N + 27) / 28;
-        if (geom) FL_(32, 1, t); else FL_(32, 0, t);
+        if (half_d) { if (geom) FL_(32, 1, 1, t); else FL_(32, 0, 1, t); }
+        else { if (geom) FL_(32, 1, 0, t); else FL_(32, 0, 0, t); }
     }
 #undef FL_
     femfct_prof_end(ctx);

@@ -226,10 +226,11 @@ def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
 
 
 def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch):
-    """Two traffic savers of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
+    """Three traffic savers of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
     operator derived inside k_build_low_sb / k_dudt_rhs_sb instead of stored by k_ops_solidbody and read back;
-    (ii) FEMFCT_LMASK -- the exactly-zero off-diagonals of the upwind low-order operator skipped when the Jacobi
-    patches load L.  Forward + all-time adjoint (source term) at 331^2 nodes, eps != 0 as well."""
+    (ii) FEMFCT_LMASK -- the exactly-zero off-diagonals of the upwind low-order operator neither stored nor loaded
+    by the Jacobi patches; (iii) FEMFCT_HALF_D -- d_ij stored once per edge, the limiter takes d_ji from the
+    neighbour.  Forward + all-time adjoint (source term) at 331^2 nodes, eps != 0 as well."""
     nc, Nt = 330, 2
     mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
     n = mesh.nodes
@@ -240,9 +241,10 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
     c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1) + 0.1 * rng.random((Nt + 1) * n)
     for eps in (0.0, 1e-3):
         outs = []
-        for inline_ops, lmask in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        for inline_ops, lmask, half_d in (("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "0", "1"), ("1", "1", "1")):
             monkeypatch.setenv("FEMFCT_INLINE_OPS", inline_ops)
             monkeypatch.setenv("FEMFCT_LMASK", lmask)
+            monkeypatch.setenv("FEMFCT_HALF_D", half_d)
             prob = solvers.SolidBodyDrift(mesh, Nt, dt, eps=eps, order=hp.ORDER_VERTEX)
             try:
                 assert prob.ctx.uses_bandwidth_tiles(1)

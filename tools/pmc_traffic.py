@@ -17,11 +17,13 @@ import re
 import statistics
 import sys
 
-CLASS = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_tile_jacobi": "jacobi", "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb", "k_strip_jacobi": "jacobi",
-         "k_strip4_jacobi": "jacobi", "k_strip4_cheb": "cheb", "k_strip4_cheb_mass": "cheb", "k_tile_build_jacobi": "jacobi", "k_tile_dudt_cheb": "dudt_rhs",
-         "k_tile_cheb_flux_limit": "flux",
-         "k_dudt_rhs": "dudt_rhs", "k_cheb": "cheb", "k_tile_cheb": "cheb", "k_strip_cheb": "cheb",
-         "k_flux": "flux", "k_tile_flux_limit": "flux", "k_limit": "limit", "k_ops_solidbody": "assemble"}
+# kernel -> class, separately for the product path at the roofline size (fused multi-sweep kernels, operator derived
+# in the kernels) and for the fusions-off pass of bench.py (one-sweep kernels); both run in the same bench.py process
+PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_dudt_rhs_sb": "dudt_rhs", "k_strip4_cheb_mass": "cheb",
+           "k_strip4_cheb": "cheb", "k_tile_flux_limit": "flux", "k_tile_jacobi": "jacobi", "k_tile_cheb": "cheb",
+           "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb"}
+ONE_SWEEP = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_dudt_rhs": "dudt_rhs", "k_cheb": "cheb", "k_flux": "flux",
+             "k_limit": "limit", "k_ops_solidbody": "assemble"}
 
 
 def load(path, counter, min_grid):
@@ -46,15 +48,17 @@ def main():
     min_grid = n // 8          # work-items: only the large-mesh launches (tile kernels: up to 4 nodes/thread)
     fa = load(fpath, "FETCH_SIZE", min_grid)
     wa = load(wpath, "WRITE_SIZE", min_grid)
-    rows, traffic = [], {}
+    rows, traffic, traffic1 = [], {}, {}
     for k in sorted(fa):
         f = statistics.mean(fa[k]) * 1024
         w = statistics.mean(wa.get(k, [0.0])) * 1024
         hbm = 2 * f + w
         rows.append(dict(kernel=k, launches=len(fa[k]), fetch_size_bytes_raw=f, write_size_bytes=w,
                          hbm_bytes_per_launch=hbm, hbm_bytes_per_row=hbm / n))
-        if k in CLASS:
-            traffic[CLASS[k]] = hbm
+        if k in PRODUCT:
+            traffic[PRODUCT[k]] = hbm
+        if k in ONE_SWEEP:
+            traffic1[ONE_SWEEP[k]] = hbm
     with open(prefix + "_pmc_traffic.csv", "w", newline="") as f:
         wr = csv.DictWriter(f, fieldnames=list(rows[0]))
         wr.writeheader()
@@ -66,7 +70,7 @@ def main():
     tj = os.path.join(os.path.dirname(prefix), "traffic.json")
     data = json.load(open(tj)) if os.path.exists(tj) else {}
     data = {k: v for k, v in data.items() if isinstance(v, dict) and "bytes_per_launch" in v}   # drop unstamped records
-    data[f"n{n}"] = {"source_sha16": source_sha16(), "bytes_per_launch": traffic,
+    data[f"n{n}"] = {"source_sha16": source_sha16(), "bytes_per_launch": traffic, "one_sweep_bytes_per_launch": traffic1,
                      "method": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate rocprofv3 --pmc passes"}
     json.dump(data, open(tj, "w"), indent=1, sort_keys=True)
     for r in rows:
