@@ -1570,14 +1570,25 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     const unsigned pxy = strip4_patch(remap);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { g[r] = strip4_node(N, r, H, pxy); nzbits[r] = 0x3fu; }
+    // order of issue: the mask words, then the 12 loads that do not depend on them (diagonal, b, x), and only then
+    // -- after waiting for the (older) mask loads alone -- the 24 masked loads of L: the mask round trip is covered
+    unsigned long long mw[4][W - 1];
     if (lmask) {
-        unsigned long long mw[4][W - 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {      // all 12 (16-byte) mask loads first: one round trip, not four
             const unsigned long long* src = lmask + ((int64_t)bz * nwords + (g[r].i >> 6)) * (W - 1);
 #pragma unroll
             for (int s = 0; s < W - 1; ++s) mw[r][s] = src[s];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = g[r].i;              // lanes outside the mesh read node 0's (finite) data and are zeroed below
+        dg[r] = L[i];
+        bv[r] = b_[voff + i];
+        x[r] = xin[i];
+    }
+    if (lmask) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             unsigned bits = 0;
@@ -1588,15 +1599,12 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int i = g[r].i;              // lanes outside the mesh read node 0's (finite) data and are zeroed below
-        dg[r] = L[i];
+        const int i = g[r].i;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             const int64_t off = ((nzbits[r] >> (s - 1)) & 1u) ? (int64_t)s * n + i : zoff;   // one load either way
             lv[r][s - 1] = L[off];
         }
-        bv[r] = b_[voff + i];
-        x[r] = xin[i];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
