@@ -53,6 +53,12 @@ def _slotted_disc(a1, a2, deltax, slit=0.05):
     return ((R < 1 / 3) & ((np.abs(X) > slit) | (Y > 0.5))).astype(np.float64).reshape(-1)
 
 
+def _fusion_knobs_on():
+    import os
+    return all(os.environ.get(k, "1") != "0" for k in ("FEMFCT_TILES", "FEMFCT_STRIPS", "FEMFCT_IMPLICIT", "FEMFCT_TILE4",
+                                                       "FEMFCT_T4_DPP"))
+
+
 def _report(name, **errs):
     print(f"[fullsize] {name}: " + ", ".join(f"{k}={v:.3e}" for k, v in errs.items()))
 
@@ -212,7 +218,8 @@ def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
 
     prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1.0, 1.0, nc), Nt, dt, order=hp.ORDER_VERTEX)
     try:
-        assert prob.ctx.uses_bandwidth_tiles(1), "this size must select the 64-patch kernels"
+        if _fusion_knobs_on():           # (a tuning knob may have switched the fused kernels off: then the row kernels face the oracle)
+            assert prob.ctx.uses_bandwidth_tiles(1), "this size must select the 64-patch kernels"
         uk = np.zeros((Nt + 1) * n)
         uk[:n] = u0
         prob.solve_state(c, uk)
@@ -247,7 +254,8 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
             monkeypatch.setenv("FEMFCT_HALF_D", half_d)
             prob = solvers.SolidBodyDrift(mesh, Nt, dt, eps=eps, order=hp.ORDER_VERTEX)
             try:
-                assert prob.ctx.uses_bandwidth_tiles(1)
+                if _fusion_knobs_on():
+                    assert prob.ctx.uses_bandwidth_tiles(1)
                 uk = np.zeros((Nt + 1) * n)
                 uk[:n] = u0
                 prob.solve_state(c, uk)
