@@ -45,7 +45,9 @@ def load(path, counter, min_grid):
 
 def main():
     fpath, wpath, n, prefix = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    min_grid = n // 8          # work-items: only the large-mesh launches (tile kernels: up to 4 nodes/thread)
+    min_grid = n // 16         # work-items: only the large-mesh launches (row kernels: at most 2048 blocks x 256 threads;
+                               # tile kernels: up to 4 nodes per thread); the PMC runs use --batched= so that no batch of
+                               # small trajectories reaches this size
     fa = load(fpath, "FETCH_SIZE", min_grid)
     wa = load(wpath, "WRITE_SIZE", min_grid)
     rows, traffic, traffic1 = [], {}, {}
