@@ -59,19 +59,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s is ach
 # vertex order: index-free addressing, no column-index bytes; ELL width 7 = diagonal + 6).  Every
 # array a launch reads or writes is counted once, whatever the number of sweeps it performs.
 # ---------------------------------------------------------------------------------------------
-def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False):
+def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False, half_d: bool = False, l_nonzero: float = 1.0):
+    """l_nonzero: share of L's off-diagonal entries that are non-zero -- in the bandwidth regime the vanishing ones are
+    neither stored by k_build_low nor loaded by k_strip4_jacobi (femfct_lowop_nonzero_fraction), so they are no part
+    of the bytes a launch needs.  half_d: D stored once per edge (three slots instead of six, no diagonal)."""
+    l_bytes = 8 + 6 * 8 * l_nonzero                 # diagonal + the off-diagonals that exist
+    d_bytes = 3 * 8 if half_d else 7 * 8
     b = {
         "assemble": 7 * 8 * 3 + 6 * 4 + 8,          # Ad, Arot, A(write), neighbour indices, c   (per level)
-        "build_low": 7 * 8 * 3 + 8 * 4,             # A, L(w), D(w), ml, u_n, b(w), x0(w)
-        "jacobi": 7 * 8 + 8 * 3,                    # L, b, x_in, x_out(w)  (all of L: the zero mask is not credited)
+        "build_low": 7 * 8 + l_bytes + d_bytes + 8 * 4,     # A, L(w), D(w), ml, u_n, b(w), x0(w)
+        "jacobi": l_bytes + 8 * 3,                  # L, b, x_in, x_out(w)
         "dudt_rhs": 7 * 8 + 8 * 5,                  # A, u_L, M_diag, r(w), u_L copy(w), y1(w)
     }
     if inline_ops:                                  # operator derived in the kernels from Arot + the control's 1-ring
-        b["build_low"] = 7 * 8 * 3 + 8 * 5 + 1      # Arot, L(w), D(w), c, ml, u_n, b(w), x0(w), zero mask(w)
+        b["build_low"] = 7 * 8 + l_bytes + d_bytes + 8 * 5 + 1   # Arot, L(w), D(w), c, ml, u_n, b(w), x0(w), zero mask(w)
         b["dudt_rhs"] = 7 * 8 + 8 * 6               # Arot, c, u_L, M_diag, r(w), u_L copy(w), y1(w)
     if fused:
         b["cheb"] = 8 * 4 + (0 if geom_mass else 7 * 8)            # b, y_mid, y_old|y_old(w), y_new(w) [+ M]
-        b["flux"] = 6 * 8 + 8 * 4 + (0 if geom_mass else 6 * 8)     # D, u_L, du, ml, u_out(w) [+ M]: F never stored
+        b["flux"] = (3 * 8 if half_d else 6 * 8) + 8 * 4 + (0 if geom_mass else 6 * 8)   # D, u_L, du, ml, u_out(w) [+ M]: F never stored
     else:
         b["cheb"] = 7 * 8 + 8 * 4                                   # M, b, y_mid, y_old, y_new(w)
         b["flux"] = 6 * 8 * 3 + 8 * 5                               # M, D, F(w), u_L, du, ml, R+(w), R-(w)
@@ -467,7 +472,10 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     step_ms, rep, sweeps = _profiled_forward(prob, ctx, d_c, d_u, steps)
     fused_flux = rep["limit"][1] == 0
     inline_ops = rep["assemble"][1] == 0           # no stored operator: k_build_low_sb / k_dudt_rhs_sb
-    bpr = launch_bytes_per_row(fused=regime >= 2 and fused_flux, geom_mass=geom, inline_ops=inline_ops)
+    half_d = regime == 3 and os.environ.get("FEMFCT_HALF_D", "1") != "0"
+    l_nonzero = ctx.lowop_nonzero_fraction()       # 1.0 unless the zero mask is in force
+    bpr = launch_bytes_per_row(fused=regime >= 2 and fused_flux, geom_mass=geom, inline_ops=inline_ops, half_d=half_d,
+                               l_nonzero=l_nonzero)
     units = {"assemble": steps}
     one_sweep_units = {"jacobi": sweeps, "cheb": 19 * steps, "flux": steps}
     kernels = _kernel_table(rep, bpr, n, units, traffic, one_sweep_units)
@@ -485,12 +493,14 @@ def roofline(hp, solvers, n_cells, steps, device_id):
            "traffic": dom.get("traffic_bytes_per_launch"), "traffic_source": traffic_note,
            "traffic_frac_incl_infinity_cache": dom.get("traffic_frac_incl_infinity_cache"),
            "one_sweep_equiv_GBps": dom.get("one_sweep_equiv_GBps"),
-           "definition": "achieved = compulsory bytes of one launch as executed (each array once; L once per "
-                         "multi-sweep launch) / mean launch time by HIP events; frac = achieved / 8 TB/s",
+           "definition": "achieved = compulsory bytes of one launch as executed (each array once; L once per multi-sweep "
+                         "launch, without its exactly-zero off-diagonals, which are neither stored nor loaded) / mean "
+                         "launch time by HIP events; frac = achieved / 8 TB/s",
            "workload": f"synthetic square mesh {n_cells + 1}x{n_cells + 1} (n={n}), vertex order, same CFL as C2",
            "compulsory_bytes_per_launch": dom["compulsory_bytes_per_row_per_launch"] * n,
            "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "source_sha16": sha,
            "operator": "derived inside k_build_low_sb / k_dudt_rhs_sb" if inline_ops else "stored by k_ops_solidbody",
+           "low_order_offdiag_nonzero_fraction": l_nonzero, "d_stored_once_per_edge": half_d,
            "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms, "jacobi_sweeps_per_step": sweeps / steps,
            "step": {"compulsory_bytes": step_bytes, "compulsory_GBps": step_bytes / (1e6 * step_ms),
                     "compulsory_frac": step_bytes / (1e6 * step_ms) / HBM_PEAK_GBS,

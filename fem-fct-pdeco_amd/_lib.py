@@ -73,6 +73,7 @@ SIGNATURES = {
     "femfct_set_graphs": (C.c_int, [_p, C.c_int]),
     "femfct_set_fusion": (C.c_int, [_p, C.c_int, C.c_int]),
     "femfct_kernel_regime": (C.c_int, [_p, _i]),
+    "femfct_lowop_nonzero_fraction": (C.c_int, [_p, _dp]),
     "femfct_set_profiling": (C.c_int, [_p, C.c_int]),
     "femfct_profile_report": (C.c_int, [_p, _p, _p, _i]),
     "femfct_malloc": (C.c_int, [_p, C.POINTER(_p), C.c_size_t]),

@@ -41,6 +41,20 @@ __global__ void k_gather_ell_to_csr(int64_t nnz, const int32_t* __restrict__ map
     if (k < nnz) v[k] = ell[map[k]];
 }
 
+// bits set in the zero mask of the low-order operator (one workgroup; diagnostic, not on the hot path)
+__global__ void k_mask_popcount(int64_t words, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s[256];
+    unsigned long long c = 0;
+    for (int64_t k = threadIdx.x; k < words; k += blockDim.x) c += (unsigned long long)__popcll(mask[k]);
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
 template <class T>
 int dev_alloc(femfct_ctx* ctx, T** p, size_t count) {
     if (*p) { hipFree(*p); *p = nullptr; }
@@ -354,6 +368,28 @@ int femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch) {
     StripPlan sp;
     if (femfct_strip_plan(ctx, &sp)) return FEMFCT_REGIME_STRIPS;
     return FEMFCT_REGIME_ROWS;
+}
+
+// Share of the off-diagonal entries of the most recent low-order operator (batch member 0) that are non-zero, i.e.
+// that the 64-patch Jacobi launches actually load; 1.0 when the zero mask is not in use.  Diagnostic for bench.py:
+// the compulsory bytes of a launch "as executed" must not count entries the kernel never touches.  Synchronises.
+int femfct_lowop_nonzero_fraction(femfct_ctx* ctx, double* fraction_host) {
+    FEMFCT_ENTER(ctx);
+    ARG_TRY(ctx, fraction_host, "null argument");
+    *fraction_host = 1.0;
+    if (!ctx->d_Lmask || ctx->n <= 0 || !ctx->l_mask || !femfct_tile4_wanted(ctx, 1) || !ctx->t4_dpp ||
+        ctx->solver != FEMFCT_SOLVER_JACOBI)
+        return FEMFCT_OK;
+    const int64_t words = (((int64_t)ctx->n + 63) / 64) * 6;
+    unsigned long long* d_cnt = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_mask_popcount, dim3(1), dim3(256), 0, ctx->stream, words, ctx->d_Lmask + 1, d_cnt);
+    unsigned long long cnt = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_cnt);
+    *fraction_host = (double)cnt / (6.0 * (double)ctx->n);
+    return FEMFCT_OK;
 }
 
 int femfct_set_graphs(femfct_ctx* ctx, int enable) {

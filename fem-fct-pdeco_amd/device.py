@@ -144,6 +144,12 @@ class Context:
         """_lib.REGIME_*: the Jacobi / Chebyshev kernel family a step with ``batch`` members runs."""
         return lib.femfct_kernel_regime(self.handle, int(batch))
 
+    def lowop_nonzero_fraction(self) -> float:
+        """share of the low-order operator's off-diagonals the bandwidth-regime Jacobi launches load (1.0: all)"""
+        out = C.c_double(1.0)
+        check(self.handle, lib.femfct_lowop_nonzero_fraction(self.handle, C.byref(out)))
+        return float(out.value)
+
     def uses_bandwidth_tiles(self, batch=1) -> bool:
         return self.kernel_regime(batch) == _lib.REGIME_PATCH64
 
