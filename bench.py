@@ -493,6 +493,9 @@ def roofline(hp, solvers, n_cells, steps, device_id):
            "traffic": dom.get("traffic_bytes_per_launch"), "traffic_source": traffic_note,
            "traffic_frac_incl_infinity_cache": dom.get("traffic_frac_incl_infinity_cache"),
            "one_sweep_equiv_GBps": dom.get("one_sweep_equiv_GBps"),
+           # the same launch priced as if the vanishing entries of L had to be streamed (dense 7-slot rows: 80 B/row)
+           "frac_counting_zero_entries": (ONE_SWEEP_BYTES[dom_name] * n / (1e6 * dom["avg_launch_ms"]) / HBM_PEAK_GBS
+                                          if dom_name == "jacobi" else None),
            "definition": "achieved = compulsory bytes of one launch as executed (each array once; L once per multi-sweep "
                          "launch, without its exactly-zero off-diagonals, which are neither stored nor loaded) / mean "
                          "launch time by HIP events; frac = achieved / 8 TB/s",
