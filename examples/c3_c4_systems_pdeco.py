@@ -4,7 +4,11 @@
 chemotaxis_FCT_PDECO_AT_refactored.py).  Targets: the build's own forward solve at the true control, as the
 reference workflow does (chemotaxis_generate_pattern_FCT.py:90-96).
 
-usage: python examples/c3_c4_systems_pdeco.py {schnak,chtxs,nonlinear} [--iters 5] [--optim alltime|finaltime]"""
+`--named-c3` (with `schnak`): the set-up of the script BASELINE config 3 names, Schnak_FCT_PDECO_alltime.py:22-55 -- dx = 0.02
+(51 x 51), dt = 2e-3, T = 0.2, all-time misfit, control box [0, 0.5], wind (-(y-.5), (x-.5)) * sin(2 pi t) re-assembled
+per step (a per-level factor on the device).
+
+usage: python examples/c3_c4_systems_pdeco.py {schnak,chtxs,nonlinear} [--iters 5] [--optim alltime|finaltime] [--named-c3]"""
 import argparse
 import time
 
@@ -16,23 +20,33 @@ ap = argparse.ArgumentParser()
 ap.add_argument("problem", choices=["schnak", "chtxs", "nonlinear"])
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--optim", default=None)
+ap.add_argument("--named-c3", action="store_true")
 args = ap.parse_args()
 
 dx, dt, T = 0.025, 5e-4, 0.1
+wind_kw = {}
+if args.named_c3:
+    if args.problem != "schnak":
+        raise SystemExit("--named-c3 goes with the schnak problem")
+    dx, dt, T = 0.02, 2e-3, 0.2
+    wind_kw = dict(wind=lambda x, y: (-(y - 0.5), (x - 0.5)), wind_scale=lambda t: np.sin(2 * np.pi * t))
+    args.optim = args.optim or "alltime"
 V = hp.SquareMeshP1(0.0, 1.0, round(1 / dx))
 n, Nt = V.nodes, round(T / dt)
 tl = (Nt + 1) * n
 z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
 if args.problem == "schnak":
     ic = hp.schnak_sys_IC(0, 1, dx, n, V.vertex_to_dof)
-    full = hp.solve_schnak_system(np.full(tl, 0.1), z(ic[0]), z(ic[1]), V, n, Nt, dt, None)          # true control a = 0.1
+    full = hp.solve_schnak_system(np.full(tl, 0.1), z(ic[0]), z(ic[1]), V, n, Nt, dt, None, **wind_kw)   # true control a = 0.1
 elif args.problem == "chtxs":
     ic = hp.chtxs_sys_IC(0, 1, dx, n, V.vertex_to_dof)
     full = hp.solve_chtxs_system(np.full(tl, 10.0), z(ic[0]), z(ic[1]), V, n, Nt, dt, None)           # c = 100 * r, r = 1/10
 else:
     ic = (hp.nonlinear_equation_IC(0, 1, dx, n, V.vertex_to_dof),)
     full = (hp.solve_nonlinear_equation(np.full(tl, 0.5), z(ic[0]), None, V, n, Nt, dt, None)[0],)
-opts = dict(max_iter_GD=args.iters, tol=0.0)
+opts = dict(max_iter_GD=args.iters, tol=0.0, **wind_kw)
+if args.named_c3:
+    opts.update(c_lower=0.0, c_upper=0.5)
 if args.optim:
     opts["optim"] = args.optim
 optim = opts.get("optim", pdeco.DEFAULTS[args.problem]["optim"])

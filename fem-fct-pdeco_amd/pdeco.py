@@ -41,9 +41,14 @@ class SystemPDECO:
     """One optimisation problem on one GPU.  ``V``: mesh descriptor (stands in for the dolfin
     FunctionSpace); host vectors are in FEniCS DoF order like the reference's."""
 
-    def __init__(self, problem: str, V: SquareMeshP1, num_steps: int, dt: float, device_id: int = 0, **overrides):
+    def __init__(self, problem: str, V: SquareMeshP1, num_steps: int, dt: float, device_id: int = 0, wind=None,
+                 wind_scale=None, **overrides):
+        """``wind`` / ``wind_scale`` (problem "schnak" only): the separable time-dependent wind ``s(t) w0(x)`` of the
+        script BASELINE config 3 names (Schnak_FCT_PDECO_alltime.py:55,174-175), see systems.solve_schnak_system."""
         if problem not in DEFAULTS:
             raise ValueError(f"unknown problem '{problem}' (one of {sorted(DEFAULTS)})")
+        if (wind is not None or wind_scale is not None) and problem != "schnak":
+            raise ValueError("wind / wind_scale: only the Schnakenberg driver has a time-dependent wind")
         self.problem, self.V, self.Nt, self.dt = problem, V, int(num_steps), float(dt)
         self.P = dict(DEFAULTS[problem])
         unknown = set(overrides) - set(self.P)
@@ -61,8 +66,10 @@ class SystemPDECO:
             self.eps, _, wind = get_nonlinear_eqns_params()
             self.Aw, self.AwT = self.S.convection(wind, "nonlinear")
         elif problem == "schnak":
-            self.par, wind = _schnak_par()
-            self.Aw, self.AwT = self.S.convection(wind, "schnak")
+            from .systems import _wind_factors
+            self.par, wind0 = _schnak_par()
+            self.Aw, self.AwT = self.S.convection(wind or wind0, None if wind is not None else "schnak")
+            self.wscale = _wind_factors(wind_scale, self.Nt, self.dt)
         else:
             self.par = _chtxs_par()
         self._arrays = []
@@ -114,7 +121,7 @@ class SystemPDECO:
         elif self.problem == "schnak":
             # the drivers and armijo_line_search_ref call the state solver without `rescaling`
             # (helpers.py:1685): its defaults apply, 1 (helpers.py:512) and 1/10 (helpers.py:1252)
-            self.ctx.schnak_forward(self.Aw, clev, u, v, self.Nt, self.dt, self.par, 1.0, batch=B)
+            self.ctx.schnak_forward(self.Aw, clev, u, v, self.Nt, self.dt, self.par, 1.0, batch=B, wind_scale=self.wscale)
         else:
             self.ctx.chtxs_forward(clev, u, v, self.Nt, self.dt, self.par, 0.1, batch=B)
 
@@ -123,7 +130,7 @@ class SystemPDECO:
             self.ctx.nonlinear_adjoint(self.Aw, u, tg[0], p, self.Nt, self.dt, self.eps)
         elif self.problem == "schnak":
             self.ctx.schnak_adjoint(self.AwT, u, v, tg[0], tg[1], p, q, self.Nt, self.dt, self.par,
-                                    alltime=self.P["optim"] == "alltime")
+                                    alltime=self.P["optim"] == "alltime", wind_scale=self.wscale)
         else:
             self.ctx.chtxs_adjoint(u, v, tg[0], tg[1], p, q, c, self.Nt, self.dt, self.par, self.P["rescaling"],
                                    self.P["optim"] == "alltime")
@@ -270,7 +277,8 @@ class SystemPDECO:
         return out
 
 
-def projected_gradient_descent(problem, V, ic, targets, num_steps, dt, speculative=True, device_id=0, **overrides):
+def projected_gradient_descent(problem, V, ic, targets, num_steps, dt, speculative=True, device_id=0, wind=None,
+                               wind_scale=None, **overrides):
     """One call = one run of the refactored driver ``problem`` (see module docstring)."""
-    with SystemPDECO(problem, V, num_steps, dt, device_id=device_id, **overrides) as prob:
+    with SystemPDECO(problem, V, num_steps, dt, device_id=device_id, wind=wind, wind_scale=wind_scale, **overrides) as prob:
         return prob.run(ic, targets, speculative=speculative)

@@ -40,7 +40,7 @@ def rel_err(new, old):
     return abs(new - old) / abs(old)
 
 
-def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, **overrides):
+def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, wind=None, wind_scale=None, **overrides):
     """Run the loop of the refactored driver ``problem`` in {"nonlinear", "schnak", "chtxs"}.
 
     ic = (u0,) or (u0, v0); targets = (uhat,) or (uhat, vhat) (final-time vectors or trajectories
@@ -58,7 +58,7 @@ def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, **ov
         if problem == "nonlinear":
             return traj.solve_nonlinear_equation(c, var1, var2, asm, nodes, num_steps, dt)
         if problem == "schnak":
-            return traj.solve_schnak_system(c, var1, var2, asm, nodes, num_steps, dt)
+            return traj.solve_schnak_system(c, var1, var2, asm, nodes, num_steps, dt, wind=wind, wind_scale=wind_scale)
         return traj.solve_chtxs_system(c, var1, var2, asm, nodes, num_steps, dt)
 
     def adjoint(uk, vk, pk, qk, ck):
@@ -66,7 +66,7 @@ def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, **ov
             return traj.solve_adjoint_nonlinear_equation(uk, targets[0], pk, T, asm, nodes, num_steps, dt), None
         if problem == "schnak":
             return traj.solve_adjoint_schnak_system(uk, vk, targets[0], targets[1], pk, qk, T, asm, nodes, num_steps, dt,
-                                                    None, optim)
+                                                    None, optim, wind=wind, wind_scale=wind_scale)
         return traj.solve_adjoint_chtxs_system(uk, vk, targets[0], targets[1], pk, qk, ck, T, asm, nodes, num_steps,
                                                dt, None, optim, rescaling=r)
 

@@ -13,6 +13,7 @@ EX = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
     ("c1_forward_solidbody.py", ["--steps", "5"], "difference of the two end states"),
     ("c2_solidbody_pdeco_finaltime.py", ["--iters", "1"], "PGD iterations in"),
     ("c3_c4_systems_pdeco.py", ["nonlinear", "--iters", "1"], "PGD iterations in"),
+    ("c3_c4_systems_pdeco.py", ["schnak", "--iters", "1", "--named-c3"], "schnak (alltime): 1 PGD iterations in"),
     ("c5_beta_sweep.py", ["--iters", "1"], "beta = "),
 ])
 def test_example_runs(script, args, needle):

@@ -70,6 +70,35 @@ def test_pgd_loop_matches_oracle_loop(hp, problem, Nt, dt, opts, speculative):
         assert rel(got[key], ref[key]) < 1e-7, key
 
 
+def test_pgd_schnak_alltime_with_the_time_dependent_wind_of_config3(hp):
+    """BASELINE config 3 as the named script sets it up (Schnak_FCT_PDECO_alltime.py:22-55,174-175): all-time misfit,
+    control box [0, 0.5], wind (-(y-.5), (x-.5)) * sin(2 pi t) re-assembled per step -- the whole projected-gradient
+    loop on the device against the oracle loop (targets: the oracle's forward solve at the true control a = 0.1)."""
+    from oracle import pdeco as opdeco, traj as otraj
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    nc, Nt, dt = 12, 8, 2e-3
+    asm = P1Assembler(SquareMesh(0.0, 1.0, nc))
+    V = hp.SquareMeshP1(0.0, 1.0, nc)
+    n = V.nodes
+    rot = lambda x, y: (-(y - 0.5), (x - 0.5))
+    s_t = lambda t: np.sin(2 * np.pi * 25 * t)           # faster than the script's so that 8 steps see a sign change
+    u0, v0 = hp.schnak_sys_IC(0, 1, 1.0 / nc, n, V.vertex_to_dof)
+    z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
+    ut, vt = otraj.solve_schnak_system(np.full((Nt + 1) * n, 0.1), z(u0), z(v0), asm, n, Nt, dt, wind=rot, wind_scale=s_t)
+    opts = dict(max_iter_GD=3, max_iter_armijo=14, optim="alltime", c_lower=0.0, c_upper=0.5)
+    ref = opdeco.projected_gradient_descent("schnak", asm, asm.mass(), (u0, v0), (ut.copy(), vt.copy()), Nt, dt,
+                                            wind=rot, wind_scale=s_t, **opts)
+    got = hp.projected_gradient_descent("schnak", V, (u0, v0), (ut.copy(), vt.copy()), Nt, dt, wind=rot, wind_scale=s_t,
+                                        **opts)
+    assert got["it"] == ref["it"] and got["armijo_its"] == ref["armijo_its"] and got["restored"] == ref["restored"]
+    np.testing.assert_allclose(got["cost"], ref["cost"], rtol=1e-9)
+    for key in ("c", "u", "v", "p", "q"):
+        assert rel(got[key], ref[key]) < 1e-7, key
+    with pytest.raises(ValueError):
+        hp.projected_gradient_descent("nonlinear", V, (u0,), (ut[Nt * n:],), Nt, dt, wind_scale=s_t)
+
+
 def test_pgd_argument_errors(hp):
     V = hp.SquareMeshP1(0.0, 1.0, 6)
     with pytest.raises(ValueError):
