@@ -4,9 +4,11 @@
 chemotaxis_FCT_PDECO_AT_refactored.py).  Targets: the build's own forward solve at the true control, as the
 reference workflow does (chemotaxis_generate_pattern_FCT.py:90-96).
 
-`--named-c3` (with `schnak`): the set-up of the script BASELINE config 3 names, Schnak_FCT_PDECO_alltime.py:22-55 -- dx = 0.02
-(51 x 51), dt = 2e-3, T = 0.2, all-time misfit, control box [0, 0.5], wind (-(y-.5), (x-.5)) * sin(2 pi t) re-assembled
-per step (a per-level factor on the device).
+`--named-c3` (with `schnak`): BASELINE config 3 as the script it names sets the problem up (Schnak_FCT_PDECO_alltime.py:22-55,
+174-175): all-time misfit, control box [0, 0.5], wind (-(y-.5), (x-.5)) * sin(2 pi t) re-assembled per step (a per-level
+factor on the device), on BASELINE's grid dx = 0.025, dt = 5e-4 (the script's own literals, dx = 0.02 / dt = 2e-3, put the
+omega1-scaled convection at CFL 7: far outside the scheme's dt restriction, where the low-order solve falls back to
+BiCGStab and the adjoint operator, with its indefinite reaction matrix, is no longer solved to 1e-13).
 
 usage: python examples/c3_c4_systems_pdeco.py {schnak,chtxs,nonlinear} [--iters 5] [--optim alltime|finaltime] [--named-c3]"""
 import argparse
@@ -28,7 +30,6 @@ wind_kw = {}
 if args.named_c3:
     if args.problem != "schnak":
         raise SystemExit("--named-c3 goes with the schnak problem")
-    dx, dt, T = 0.02, 2e-3, 0.2
     wind_kw = dict(wind=lambda x, y: (-(y - 0.5), (x - 0.5)), wind_scale=lambda t: np.sin(2 * np.pi * t))
     args.optim = args.optim or "alltime"
 V = hp.SquareMeshP1(0.0, 1.0, round(1 / dx))

@@ -338,6 +338,8 @@ int femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters
     ARG_TRY(ctx, solver == FEMFCT_SOLVER_JACOBI || solver == FEMFCT_SOLVER_BICGSTAB, "unknown solver");
     ARG_TRY(ctx, rel_tol > 0 && rel_tol < 1 && max_iters >= 1, "bad tolerance / iteration cap");
     ctx->solver = solver;
+    ctx->solver_user = solver;
+    ctx->kind_low_bicg.clear();
     ctx->rel_tol = rel_tol;
     ctx->max_iters = max_iters;
     if (ctx->sweep_budget > max_iters) ctx->sweep_budget = max_iters;

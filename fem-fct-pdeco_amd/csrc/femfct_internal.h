@@ -58,7 +58,9 @@ struct femfct_ctx {
     bool have_mass = false;
 
     // solver settings
-    int solver = FEMFCT_SOLVER_JACOBI;
+    int solver = FEMFCT_SOLVER_JACOBI;       // low-order solver of the sweep in progress
+    int solver_user = FEMFCT_SOLVER_JACOBI;  // what femfct_set_solver asked for
+    std::set<int> kind_low_bicg;             // sweep kinds whose Jacobi iteration did not contract: BiCGStab from then on
     double rel_tol = 1e-13;
     int max_iters = 400;
     int sweep_budget = 48;      // adaptive: sweeps enqueued per step (stand-alone femfct_fct_step)

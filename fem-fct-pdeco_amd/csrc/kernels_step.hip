@@ -611,8 +611,7 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
 
 // the drift-control operator may be derived inside the step kernels instead of being passed as a matrix
 bool femfct_inline_ops_wanted(const femfct_ctx* ctx, int32_t batch) {
-    return ctx->inline_ops && ctx->structured && ctx->implicit_cols && ctx->W == 7 && ctx->solver == FEMFCT_SOLVER_JACOBI &&
-           femfct_tile4_wanted(ctx, batch);
+    return ctx->inline_ops && ctx->structured && ctx->implicit_cols && ctx->W == 7 && femfct_tile4_wanted(ctx, batch);
 }
 
 int femfct_enqueue_step_mat(femfct_ctx* ctx, MatRef A, const double* N, int32_t nshared, VecRef rhs,

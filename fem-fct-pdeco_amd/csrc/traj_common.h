@@ -56,7 +56,18 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
     // budgets are remembered per kind of sweep: the forward and the adjoint operator of a problem
     // need different sweep counts, and a shared budget would make them evict each other
     if (!ctx->kind_budget.count(kind)) ctx->kind_budget[kind] = 48;
+    struct RestoreSolver {       // the effective solver is per kind of sweep; the user's choice comes back on every exit
+        femfct_ctx* c;
+        ~RestoreSolver() { c->solver = c->solver_user; }
+    } restore_solver{ctx};
     for (;;) {
+        // a kind whose operator lies outside the scheme's dt restriction (Jacobi does not contract: the reference's
+        // spsolve does not care, helpers.py:1782) is solved with Jacobi-preconditioned BiCGStab from then on
+        ctx->solver = ctx->kind_low_bicg.count(kind) ? FEMFCT_SOLVER_BICGSTAB : ctx->solver_user;
+        if (ctx->solver == FEMFCT_SOLVER_BICGSTAB) {
+            int rk = femfct_ensure_krylov_ws(ctx, batch);
+            if (rk != FEMFCT_OK) return rk;
+        }
         // species solves: Chebyshev (structured mesh) and BiCGStab keep separate iteration budgets
         const bool cheb = krylov && femfct_species_cheb(ctx, kind);
         const int kkey = cheb ? kind : kind + 1000;
@@ -92,7 +103,10 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         for (const StepCtl& c : ctx->h_log) {
             if (c.iters > worst) coarse = (c.flags & FEMFCT_FLAG_COARSE_ITERS) != 0;
             worst = std::max(worst, c.iters);
-            if (c.flags & FEMFCT_FLAG_SOLVER_BUDGET) { short_budget = true; worst_res = std::max(worst_res, c.resid); }
+            if (c.flags & FEMFCT_FLAG_SOLVER_BUDGET) {
+                short_budget = true;
+                worst_res = (c.resid == c.resid) ? std::max(worst_res, c.resid) : INFINITY;   // NaN: diverged
+            }
         }
         if (krylov) {
             const KrylovCtl* kl = (const KrylovCtl*)ctx->h_klog.data();
@@ -134,10 +148,25 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         }
         if (short_budget) {
             ctx->kind_fail[kind] = std::max(ctx->kind_fail.count(kind) ? ctx->kind_fail[kind] : 0, budget);
+            // no contraction at all (residual not below ||b|| after a whole budget, or not a number), or the sweep cap
+            // reached: hand this kind of sweep to BiCGStab and repeat it
+            const bool hopeless = !(worst_res < 1.0) || budget >= ctx->max_iters;
+            if (hopeless && ctx->solver == FEMFCT_SOLVER_JACOBI) {
+                if (getenv("FEMFCT_DEBUG"))
+                    fprintf(stderr, "[femfct] sweep kind %d: Jacobi residual %.3e after %d sweeps -> BiCGStab\n", kind,
+                            worst_res, budget);
+                ctx->kind_low_bicg.insert(kind);
+                ctx->kind_budget[kind] = 40;
+                ctx->kind_fail.erase(kind);
+                ctx->kind_good.erase(kind);
+                femfct_drop_graphs(ctx);
+                continue;
+            }
             if (budget >= ctx->max_iters)
                 return femfct_fail(ctx, FEMFCT_ERR_NOT_CONVERGED,
-                                   "low-order solve: residual %.3e after %d Jacobi sweeps (tol %.1e)", worst_res,
-                                   budget, ctx->rel_tol);
+                                   "low-order solve: residual %.3e after %d %s (tol %.1e)", worst_res, budget,
+                                   ctx->solver == FEMFCT_SOLVER_BICGSTAB ? "BiCGStab iterations" : "Jacobi sweeps",
+                                   ctx->rel_tol);
             // a failed attempt at fewer launches goes back to the budget that worked
             const int good = ctx->kind_good.count(kind) ? ctx->kind_good[kind] : 0;
             ctx->kind_budget[kind] = good > budget ? good : femfct_grow_budget(ctx, budget);

@@ -185,3 +185,43 @@ def test_bicgstab_handles_a_time_step_jacobi_cannot(hp):
     finally:
         ctx.set_solver(hp.SOLVER_JACOBI, 1e-13, 400)
     assert rel(u, uo) < 1e-9, info
+
+
+def test_sweep_outside_the_dt_restriction_falls_back_to_bicgstab(hp, monkeypatch):
+    """The reference's low-order solve is a direct one (spsolve, helpers.py:1782): it does not care whether the
+    operator satisfies the scheme's dt restriction.  Jacobi does: at CFL ~ 8 its iteration matrix has spectral radius
+    > 1.  The sweep must notice (no contraction after a whole budget), hand that KIND of sweep to BiCGStab, repeat it
+    and deliver the reference result -- with the M-matrix diagnostic raised, as the reference prints "3: False"."""
+    import importlib
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    from oracle import traj as otraj
+    solvers = importlib.import_module("fem-fct-pdeco_amd.solvers")
+    nc, Nt = 20, 4
+    dt = 8.0 * (2.0 / nc) / (40 / np.pi)              # CFL = |w| dt / h ~ 8 at the boundary of the rotating field
+    omesh = SquareMesh(-1, 1, nc)
+    asm = P1Assembler(omesh)
+    n = omesh.nodes
+    rng = np.random.default_rng(8)
+    u0 = np.exp(-20 * ((omesh.x + 0.3) ** 2 + (omesh.y - 0.2) ** 2))[omesh.dof_to_vertex]
+    ck = 0.5 * rng.random((Nt + 1) * n)
+    sb = otraj.SolidBody(asm, om=np.pi / 40)
+    uo = np.zeros((Nt + 1) * n); uo[:n] = u0
+    otraj.solidbody_forward(sb, ck, uo, n, Nt, dt)
+    po = otraj.solidbody_adjoint(sb, ck, uo, 0.9 * uo[Nt * n:], np.zeros_like(uo), n, Nt, dt)
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1, 1, nc), Nt, dt)
+    try:
+        ug = np.zeros((Nt + 1) * n); ug[:n] = u0
+        prob.solve_state(ck, ug)
+        log = prob.solver_log(1)
+        assert np.all(log["flags"] & hp.FLAG_MMATRIX_ROWSUM)
+        assert not np.any(log["flags"] & hp.FLAG_SOLVER_BUDGET) and log["solver_resid"].max() <= 1e-13
+        assert np.linalg.norm(ug - uo) / np.linalg.norm(uo) < 1e-9
+        pg = prob.solve_adjoint(ck, ug, 0.9 * uo[Nt * n:], np.zeros_like(ug))
+        assert np.linalg.norm(pg - po) / np.linalg.norm(po) < 1e-9
+        # the choice is remembered per kind of sweep: a second forward sweep goes straight to BiCGStab and agrees
+        ug2 = np.zeros((Nt + 1) * n); ug2[:n] = u0
+        prob.solve_state(ck, ug2)
+        assert np.array_equal(ug2, ug)
+    finally:
+        prob.close()
