@@ -1754,6 +1754,9 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
             const int ntri = 2 * c00 + c10 + c01 + 2 * c11;
             pc[r] = (c00 + c01) | ((2 * c00) << 2) | ((c00 + c10) << 4) | ((c10 + c11) << 6) | ((2 * c11) << 8) | ((c11 + c01) << 10);
             cw[r] = 1.0 / (2.0 * md_scale * ntri);
+            // interior rows weight every neighbour by two: (2 sum) cw == sum (2 cw) to the bit (scaling by two is exact),
+            // so the factor moves out of the sweeps
+            if (pc[r] == 0xAAA) cw[r] = 2.0 * cw[r];
             bv[r] = b_[voff + g[r].i] * (12.0 / (md_scale * ntri * h * h));
             if (ymid_) ym[r] = ymid_[voff + g[r].i];
             if (yold_) yo[r] = yold_[voff + g[r].i];
@@ -1772,10 +1775,10 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double sum;
-            if (pc[r] == 0xAAA) {          // interior node: all six edges carry two triangles
-                sum = 2.0 * (((STRIP4_NB(ym, above, below, r, 0) + STRIP4_NB(ym, above, below, r, 1)) +
-                              (STRIP4_NB(ym, above, below, r, 2) + STRIP4_NB(ym, above, below, r, 3))) +
-                             (STRIP4_NB(ym, above, below, r, 4) + STRIP4_NB(ym, above, below, r, 5)));
+            if (pc[r] == 0xAAA) {          // interior node: all six edges carry two triangles (the 2 sits in cw[r])
+                sum = ((STRIP4_NB(ym, above, below, r, 0) + STRIP4_NB(ym, above, below, r, 1)) +
+                       (STRIP4_NB(ym, above, below, r, 2) + STRIP4_NB(ym, above, below, r, 3))) +
+                      (STRIP4_NB(ym, above, below, r, 4) + STRIP4_NB(ym, above, below, r, 5));
             } else {
                 sum = 0.0;
 #pragma unroll
