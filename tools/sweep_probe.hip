@@ -120,6 +120,71 @@ static void run(const char* name, const double* in, double* out, int wgs, int K)
            name, K, best, best0, us_per_wg_sweep, us_per_wg_sweep * 2400.0 / 4.0);
 }
 
+// Chebyshev-on-the-mass-matrix sweep (k_strip4_cheb_mass, interior rows): six-neighbour sum, two FMAs, the three-term
+// update with the previous iterate.  CHAIN 0: the product's expression order; 1: the sum as two independent halves and
+// the update split so that no dependent chain is longer than four operations
+template <int CHAIN>
+__global__ void __launch_bounds__(1024) k_cheb_sweeps(const double* __restrict__ in, double* __restrict__ out, int K) {
+    __shared__ double top[2][16][64], bot[2][16][64];
+    const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
+    double bv[4], cw[4], ym[4], yo[4];
+    const int64_t base = ((int64_t)blockIdx.x * 1024 + threadIdx.x) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ym[r] = in[(base + r) & 0xfffff]; yo[r] = 0.5 * ym[r]; bv[r] = 0.25 * ym[r]; cw[r] = 0.066 + 1e-6 * ym[r]; }
+    const double inv_scale = 0.8;
+    for (int k = 0; k < K; ++k) {
+        const int par = k & 1;
+        bot[par][st][lx] = ym[0];
+        top[par][st][lx] = ym[3];
+        __syncthreads();
+        const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+        const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+        double e_[4], w_[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e_[r] = dpp_from_next(ym[r]); w_[r] = dpp_from_prev(ym[r]); }
+        const double ea_ = dpp_from_next(above), wb_ = dpp_from_prev(below);
+        const double wk = 1.1 + 1e-3 * k;
+        double yn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double n0 = e_[r], n1 = r < 3 ? e_[(r + 1) & 3] : ea_, n2 = r < 3 ? ym[(r + 1) & 3] : above;
+            const double n3 = w_[r], n4 = r > 0 ? w_[(r + 3) & 3] : wb_, n5 = r > 0 ? ym[(r + 3) & 3] : below;
+            if (CHAIN == 0) {
+                const double sum = ((n0 + n1) + (n2 + n3)) + (n4 + n5);
+                const double z = fma(-cw[r], sum, fma(-inv_scale, ym[r], bv[r]));
+                yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
+            } else {
+                const double sa = (n0 + n1) + n2, sb = (n3 + n4) + n5;
+                const double t = fma(-inv_scale, ym[r], bv[r]) + (ym[r] - yo[r]);
+                const double z = fma(-cw[r], sa + sb, t);
+                yn[r] = fma(wk, z, yo[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[base + r] = ym[r] + yo[r];
+}
+
+template <int CHAIN>
+static void run_cheb(const char* name, const double* in, double* out, int wgs, int K) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    float best = 1e30f, best0 = 1e30f;
+    for (int rep = 0; rep < 4; ++rep)
+        for (int pass = 0; pass < 2; ++pass) {
+            CHECK(hipEventRecord(a, 0));
+            hipLaunchKernelGGL((k_cheb_sweeps<CHAIN>), dim3(wgs), dim3(1024), 0, 0, in, out, pass ? K : 0);
+            CHECK(hipEventRecord(b, 0));
+            CHECK(hipEventSynchronize(b));
+            float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+            if (pass) best = ms < best ? ms : best; else best0 = ms < best0 ? ms : best0;
+        }
+    const double us = (best - best0) * 1e3 / K / (wgs / 256.0);
+    printf("%-44s K=%d: %8.3f ms -> %.3f us per workgroup-sweep = %.0f cycles @2.4GHz per wave-sweep\n", name, K, best, us, us * 600.0);
+}
+
 int main(int argc, char** argv) {
     const int wgs = 2048, K = argc > 1 ? atoi(argv[1]) : 64;
     double *in, *out;
@@ -141,5 +206,7 @@ int main(int argc, char** argv) {
     run<1, 1, 8, 1>("8 rows per thread, 8 waves, inner rows first", in, out, wgs, K);
     run<1, 0, 8, 0>("8 rows per thread, no LDS / barrier", in, out, wgs, K);
     run<1, 1, 16, 1>("16 rows per thread, 4 waves, inner first", in, out, wgs, K);
+    run_cheb<0>("Chebyshev sweep, product expression order", in, out, wgs, K);
+    run_cheb<1>("Chebyshev sweep, short dependent chains", in, out, wgs, K);
     return 0;
 }
