@@ -155,14 +155,19 @@ class Ranks:
     """The three things the timed region needs from torch.distributed: the all-gather of the cost
     scalars, the barrier-bracketed fence and the max-over-ranks of the elapsed time."""
 
-    def __init__(self, world, rank, local_rank, backend):
+    def __init__(self, world, rank, local_rank, backend, force=False):
         self.world, self.rank, self.local_rank, self.backend = world, rank, local_rank, backend
         self.dist = None
         self.torch = None
         if world > 1 or backend == "nccl":
             import torch
             self.torch = torch
-        if world > 1:
+        if world > 1 or force:
+            if world == 1:          # --force-dist without a launcher: a one-rank group on the loopback
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             import torch.distributed as dist
             self.dist = dist
             if backend == "nccl":                                   # RCCL on ROCm
@@ -230,6 +235,9 @@ def main():
                     help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~10 s of one core (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
     ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even with one rank (rehearses the RCCL "
+                         "calls of the N > 1 path on a one-GPU box)")
     ap.add_argument("--stub-solver", action="store_true",
                     help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no library); not a measurement")
     args = ap.parse_args()
@@ -242,7 +250,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ranks = Ranks(world, rank, local_rank, "gloo" if args.stub_solver else "nccl")
+    ranks = Ranks(world, rank, local_rank, "gloo" if args.stub_solver else "nccl", force=args.force_dist)
 
     betas = [10.0 ** (-k / 2) for k in range(8)]          # C5 sweep values
     beta = betas[rank % len(betas)] if world > 1 else 1.0  # C2: beta = 1

@@ -24,3 +24,17 @@ def test_example_runs(script, args, needle):
     if script.startswith("c1"):
         diff = float(out.stdout.split("difference of the two end states:")[1].split()[0])
         assert diff < 1e-11
+
+
+def test_bench_collectives_on_rccl_with_one_rank():
+    """The N > 1 leg of bench.py (RCCL init with device_id, all-gather of the cost on the GPU, barrier-bracketed fence,
+    all-reduce MAX of the elapsed time, destroy) executed for real on this one-GPU box as a one-rank group."""
+    import json
+    root = os.path.dirname(EX)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--force-dist", "--roofline-cells", "0", "--cpu-sample", "0", "--pgd-iters", "0", "--batched="],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["value"] > 1000 and r["cost"] > 0
