@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (rehearses the RCCL "
                          "calls of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend; gloo + fewer GPUs than ranks (ranks share GPUs round-robin) rehearses the whole "
+                         "N > 1 run, real solver included, on a one-GPU box -- not a scaling measurement")
     ap.add_argument("--stub-solver", action="store_true",
                     help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no library); not a measurement")
     args = ap.parse_args()
@@ -250,7 +253,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ranks = Ranks(world, rank, local_rank, "gloo" if args.stub_solver else "nccl", force=args.force_dist)
+    ranks = Ranks(world, rank, local_rank, "gloo" if args.stub_solver else args.backend, force=args.force_dist)
+    device_id = local_rank
+    if args.backend == "gloo" and not args.stub_solver:
+        import torch
+        device_id = local_rank % max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
 
     betas = [10.0 ** (-k / 2) for k in range(8)]          # C5 sweep values
     beta = betas[rank % len(betas)] if world > 1 else 1.0  # C2: beta = 1
@@ -274,7 +281,7 @@ def main():
         tl = (Nt + 1) * n
         # device arrays live in dolfin vertex order (the library's fast layout: index-free stencil
         # addressing + 2-D tile kernels); the DoF-ordered arrays below feed the CPU oracle
-        prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=local_rank,
+        prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=device_id,
                                       order=hp.ORDER_VERTEX)
         ctx = prob.ctx
         to_dev = lambda x: hp.reorder_vector_from_dof(x, x.size // n, n, mesh.vertex_to_dof)
@@ -346,7 +353,7 @@ def main():
 
     # ------------------------------------------------------------ roofline mesh
     if rank == 0 and args.roofline_cells > 0:
-        result["roofline"] = roofline(hp, solvers, args.roofline_cells, args.roofline_steps, local_rank)
+        result["roofline"] = roofline(hp, solvers, args.roofline_cells, args.roofline_steps, device_id)
     if rank == 0 and world == 1 and args.batched:
         # the same sweep with B independent trajectories per launch (beta values / Armijo trials on one GPU)
         result["batched"] = []

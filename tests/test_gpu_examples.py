@@ -38,3 +38,21 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["n_gpus"] == 1 and r["value"] > 1000 and r["cost"] > 0
+
+
+def test_bench_two_ranks_real_solver_on_one_gpu_gloo():
+    """bench.py --gpus 2 started without a launcher: self-launch, two ranks each with its own context and regularisation
+    value (both on this box's one GPU, collectives over gloo), all-gather of the two costs, max-over-ranks timing."""
+    import json
+    root = os.path.dirname(EX)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--backend", "gloo", "--roofline-cells", "0"], capture_output=True, text=True, timeout=400, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["parallelism"] == "beta-sweep x2"
+    J = r["costs_all_ranks"]
+    assert len(J) == 2 and J[0] > 0 and J[1] > 0 and J[0] != J[1]            # beta = 1 and 10^-1/2: different costs
+    assert "cpu_baseline" not in r and "batched" not in r                    # N = 1 legs only
