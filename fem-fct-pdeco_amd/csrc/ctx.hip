@@ -42,10 +42,13 @@ __global__ void k_gather_ell_to_csr(int64_t nnz, const int32_t* __restrict__ map
 }
 
 // bits set in the zero mask of the low-order operator (one workgroup; diagnostic, not on the hot path)
-__global__ void k_mask_popcount(int64_t words, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ out) {
+__global__ void k_mask_popcount(int64_t nbytes, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ out) {
     __shared__ unsigned long long s[256];
     unsigned long long c = 0;
+    const int64_t words = nbytes >> 3;
     for (int64_t k = threadIdx.x; k < words; k += blockDim.x) c += (unsigned long long)__popcll(mask[k]);
+    if (threadIdx.x == 0)
+        for (int64_t k = words * 8; k < nbytes; ++k) c += (unsigned long long)__popc(reinterpret_cast<const uint8_t*>(mask)[k]);
     s[threadIdx.x] = c;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -144,8 +147,11 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     A_(d_part, (size_t)batch * 4 * FEMFCT_MAX_PARTIALS);
     A_(d_ctl, (size_t)batch);
     A_(d_partk, (size_t)batch * 16 * FEMFCT_MAX_PARTIALS);
-    A_(d_Lmask, (size_t)batch * 6 * (((size_t)ctx->n + 63) / 64) + 1);   // word 0 stays zero (read in place of vanishing entries); masks from word 1
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_Lmask, 0, 8, ctx->stream));
+    {   // word 0 stays zero (read in place of vanishing entries); one mask byte per node from word 1
+        const size_t words = ((size_t)batch * (size_t)ctx->n + 7) / 8 + 1;
+        A_(d_Lmask, words);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_Lmask, 0, words * 8, ctx->stream));
+    }
     {
         TilePlan tp;
         ctx->bigpart_count = 0;
@@ -246,6 +252,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_TILE4")) ctx->tile4_mode = atoi(e);
     if (const char* e = getenv("FEMFCT_LMASK")) ctx->l_mask = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_XCD")) ctx->t4_xcd = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_T4_WALK")) ctx->t4_walk = atoi(e);   // 2: walk without the carry (measurement)
     if (const char* e = getenv("FEMFCT_INLINE_OPS")) ctx->inline_ops = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_HALF_D")) ctx->half_d = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_STAGGER_US")) {
@@ -303,6 +310,10 @@ int femfct_create(femfct_ctx** out, int device_id) {
     femfct_ctx* ctx = new (std::nothrow) femfct_ctx();
     if (!ctx) return FEMFCT_ERR_NOMEM;
     ctx->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return FEMFCT_ERR_HIP;
@@ -382,10 +393,9 @@ int femfct_lowop_nonzero_fraction(femfct_ctx* ctx, double* fraction_host) {
     if (!ctx->d_Lmask || ctx->n <= 0 || !ctx->l_mask || !femfct_tile4_wanted(ctx, 1) || !ctx->t4_dpp ||
         ctx->solver != FEMFCT_SOLVER_JACOBI)
         return FEMFCT_OK;
-    const int64_t words = (((int64_t)ctx->n + 63) / 64) * 6;
     unsigned long long* d_cnt = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
-    hipLaunchKernelGGL(k_mask_popcount, dim3(1), dim3(256), 0, ctx->stream, words, ctx->d_Lmask + 1, d_cnt);
+    hipLaunchKernelGGL(k_mask_popcount, dim3(1), dim3(256), 0, ctx->stream, (int64_t)ctx->n, ctx->d_Lmask + 1, d_cnt);   // batch member 0
     unsigned long long cnt = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -77,6 +77,8 @@ struct femfct_ctx {
     bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
+    int t4_walk = 1;            // 64-patch Jacobi: persistent workgroups walk down columns of patches, shared rows carried in LDS (FEMFCT_T4_WALK)
+    int num_cus = 256;          // compute units of the device (one 1024-thread walker each)
     int t4_xcd = 0;             // 64-patch kernels: x-neighbouring patches under the same XCD's L2 (FEMFCT_T4_XCD)
     int t4_stagger = 600 | (7 << 24);   // 64-patch Jacobi launches of >= 4 rounds: first-round stagger, ticks of 10 ns | pattern << 24
                                         // (FEMFCT_T4_STAGGER_US / _PAT; 6 us, second half of every XCD; 0 = off)
@@ -102,7 +104,7 @@ struct femfct_ctx {
     StepCtl* d_ctl = nullptr;                                         // [B]
     double* d_partk = nullptr;       // [B][16][MAX_PARTIALS] per-sweep residual partials of the last fused launch
     double* d_bigpart = nullptr;     // [B * bigpart_count] residual partials of fused launches on large grids
-    unsigned long long* d_Lmask = nullptr;   // [B][6][ceil(n/64)] bit i of slot s: l_(i,s) != 0 (written by k_build_low for the 64-patch Jacobi kernels)
+    unsigned long long* d_Lmask = nullptr;   // one zero word, then [B][n] bytes: bit s-1 of node i: l_(i,s) != 0 (written by k_build_low for the 64-patch Jacobi kernels)
     bool half_d = true;              // bandwidth regime: D stored once per edge (FEMFCT_HALF_D)
     bool inline_ops = true;          // solid-body sweeps in the bandwidth regime derive A inside the step kernels (FEMFCT_INLINE_OPS)
     bool l_mask = true;              // skip the exactly-zero off-diagonals of L when loading Jacobi patches (FEMFCT_LMASK)
@@ -237,13 +239,14 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
 int femfct_tile4_init(femfct_ctx* ctx);
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
 int femfct_tile4_tiles(const femfct_ctx* ctx, int H = 8);
+int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch);   // 0: one workgroup per patch
 int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps);
 bool femfct_single_patch(const femfct_ctx* ctx, int32_t batch);
 // launches and sweeps per launch the low-order solve of femfct_enqueue_step_mat will use for a budget
 bool femfct_jacobi_plan(const femfct_ctx* ctx, int budget, int batch, int* K, int* launches);
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
                                 int g_build, int32_t batch, int H = 8, int K = 8, int check_every = 0,
-                                const unsigned long long* lmask = nullptr);
+                                const uint8_t* lmask = nullptr);
 int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old, double* y_out,
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
                               double* bufB0, double* bufB1, int32_t batch,

@@ -109,13 +109,12 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
-                            unsigned long long* __restrict__ lmask, int half_d) {
+                            uint8_t* __restrict__ lmask, int half_d) {
     // half_d: d_ij = d_ji to the bit (max is commutative), so only the three "forward" slots E, NE, N are stored;
     // the limiter of the bandwidth regime (k_tile_flux_limit<.., HALFD = 1>) takes the other three from the neighbours
     __shared__ double smem[32];
     const int W = WT ? WT : Wrt;
     const int bz = blockIdx.y;
-    const int64_t nwords = ((int64_t)n + 63) >> 6;
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const double* Nm = N_ ? N_ + (nshared ? 0 : moff) : nullptr;
     const double* rhs = vec_ptr(rhs_ref);
@@ -138,6 +137,7 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
         const unsigned mask = nb_mask<IMP>(i, Nw);
         op.row(i, mask);
         double dsum = 0.0, rs = 0.0;
+        unsigned nzrow = 0;
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             int64_t idx = (int64_t)s * n + i;
@@ -151,14 +151,12 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
             if (Nm) l += dt * Nm[idx];
             if (!half_d || s <= 3) D[idx] = d;
             rs += l;
-            // which entries of this slot are exactly zero (the low-order operator is an upwind stencil: about half
-            // of its off-diagonals vanish): one bit per row, one 64-bit word per wave (row chunks are 64-aligned).
-            // With the mask in force its only reader (k_strip4_jacobi) never touches a vanishing entry, so those are
-            // not stored either: a 128-byte line of zeros is neither written here nor read there.
+            // which entries of this row are exactly zero (the low-order operator is an upwind stencil: about half of its
+            // off-diagonals vanish): six bits per row, one byte per node.  With the mask in force its only reader
+            // (k_strip4_jacobi[_walk]) never touches a vanishing entry, so those are not stored either: a 128-byte
+            // line of zeros is neither written here nor read there.
             if (lmask) {
-                const unsigned long long nzb = __ballot(l != 0.0);
-                if ((threadIdx.x & 63) == 0) lmask[((int64_t)bz * nwords + (i >> 6)) * (W - 1) + (s - 1)] = nzb;   // [word][slot]
-                if (l != 0.0) L[idx] = l;
+                if (l != 0.0) { L[idx] = l; nzrow |= 1u << (s - 1); }
             } else {
                 L[idx] = l;
             }
@@ -167,6 +165,7 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
         double ld = mli + dt * (op.a(0, i) + dsum);                // d_ii = -sum_j d_ij
         if (Nm) ld += dt * Nm[i];
         L[i] = ld;                  // (the diagonal of D is -dsum; the limiter reads off-diagonals only: not stored)
+        if (lmask) lmask[voff + i] = (uint8_t)nzrow;
         rs += ld;
         double ui = u[i];
         double bi = mli * ui + (rhs ? dt * rhs[i] : 0.0);
@@ -192,7 +191,7 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
-                            unsigned long long* __restrict__ lmask, int half_d) {
+                            uint8_t* __restrict__ lmask, int half_d) {
     build_low_body<WT, BS, IMP>(n, Wrt, Nw, cols, tslot, MatOp{mat_ptr(A_ref, blockIdx.y), n}, N_, nshared, rhs_ref, u_ref,
                                 rhs_bstride, u_bstride, ml, dt, L_, D_, b_, x0_, part, ctl_, lmask, half_d);
 }
@@ -204,7 +203,7 @@ __global__ void __launch_bounds__(BS) k_build_low_sb(int n, int Nw, double h, Sb
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
-                            unsigned long long* __restrict__ lmask, int half_d) {
+                            uint8_t* __restrict__ lmask, int half_d) {
     SbOp<true> op;
     op.p = sb; op.c = vec_ptr(sb.c) + blockIdx.y * sb.c_bstride; op.n = n; op.Nw = Nw; op.h = h;
     build_low_body<7, BS, 1>(n, 7, Nw, nullptr, nullptr, op, nullptr, 0, rhs_ref, u_ref, rhs_bstride, u_bstride, ml, dt,
@@ -642,8 +641,8 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
     // latency regime: the operator construction rides in the first tile-Jacobi launch
     const bool fused_build = ctx->fuse_build && tiles && !tile4 && !femfct_tile_big(ctx, tp) &&
                              ctx->solver != FEMFCT_SOLVER_BICGSTAB && (budget + tp.K - 1) / tp.K >= 2;
-    unsigned long long* lmask = (tile4 && ctx->l_mask && ctx->t4_dpp && W == 7 && ctx->solver == FEMFCT_SOLVER_JACOBI)
-                                    ? ctx->d_Lmask + 1 : nullptr;
+    uint8_t* lmask = (tile4 && ctx->l_mask && ctx->t4_dpp && W == 7 && ctx->solver == FEMFCT_SOLVER_JACOBI)
+                         ? reinterpret_cast<uint8_t*>(ctx->d_Lmask + 1) : nullptr;
     // symmetric storage of D between k_build_low and the 2-D tile limiter (both sides of this step or neither)
     const int half_d = (tile4 && ctx->half_d && ctx->structured && ctx->implicit_cols && W == 7) ? 1 : 0;
     if (sb) {
@@ -671,7 +670,8 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
         // sweeps per launch: the halo depth; a single patch runs the whole budget in one launch and stops by itself
         const int k4 = single ? budget : std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);
         units = (budget + k4 - 1) / k4;
-        part_count = big4 ? -1 : t4 * t4;
+        const int walkers = single ? 0 : femfct_tile4_walkers(ctx, h4, batch);
+        part_count = walkers > 0 ? walkers : big4 ? -1 : t4 * t4;
         ipu = k4;
         for (int s = 0; s < units; ++s)
             femfct_enqueue_tile4_jacobi(ctx, ctx->d_L, ctx->d_b, ctx->d_xa, ctx->d_xb, s, (int)g.grid.x, batch, h4, k4,

@@ -1466,10 +1466,10 @@ __device__ __forceinline__ unsigned strip4_patch(int remap) {
     return bx | (by << 16);
 }
 
-__device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned pxy) {
+__device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned pxy, int lx, int st) {
     Strip4Node g;
     const int T = T4_L - 2 * H;          // halo depth is a launch parameter (8..10): K <= H sweeps per launch
-    const int lx = threadIdx.x & 63, ly = 4 * (threadIdx.x >> 6) + r;
+    const int ly = 4 * st + r;
     const int x0 = (int)(pxy & 0xffffu) * T - H, y0 = (int)(pxy >> 16) * T - H;
     const int gx = x0 + lx, gy = y0 + ly;
     g.inside = gx >= 0 && gx < N && gy >= 0 && gy < N;
@@ -1477,6 +1477,9 @@ __device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned 
     g.owned = g.inside && lx >= H && lx < H + T && ly >= H && ly < H + T;
     g.kvalid = 0;                        // (unused: see the note on validity guards in k_strip4_jacobi)
     return g;
+}
+__device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned pxy) {
+    return strip4_node(N, r, H, pxy, threadIdx.x & 63, threadIdx.x >> 6);
 }
 
 // the six neighbour values of the thread's node r from registers / lane shifts / the two LDS rows
@@ -1519,7 +1522,7 @@ __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                 double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
                 int g_build, double rel_tol, double* __restrict__ bigpart, int H, int check_every, int stagger,
-                const unsigned long long* __restrict__ lmask, int remap) {
+                const uint8_t* __restrict__ lmask, int remap) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     __shared__ double smem[32];
@@ -1558,12 +1561,10 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     Strip4Node g[4];
     // rows pre-scaled by 1 / l_ii: x_new = bs - sum ls * x_nb;  residual of the input iterate = l_ii |x_new - x|
     double lv[4][W - 1], dg[4], bv[4], x[4];
-    // Zero masks (k_build_low: bit i of slot s = l_(i,s) != 0, stored [word][slot]): a lane whose entry is exactly
-    // zero reads one shared zero word instead of its own, so a 128-byte line of L whose 16 entries all vanish is never
-    // requested.  Each lane fetches the six mask words of its node's 64-group (48 contiguous bytes, the same two
-    // addresses across the wave: cache hits), folds them into six bits, then issues its row loads; nothing waits on
-    // a value of L until all four rows are in flight.
-    const int nwords = (n + 63) >> 6;
+    // Zero masks (k_build_low: one byte per node, bit s-1 = l_(i,s) != 0): a lane whose entry is exactly zero reads
+    // one shared zero word instead of its own, so a 128-byte line of L whose 16 entries all vanish is never requested.
+    // Each lane fetches the mask bytes of its four nodes (64 contiguous bytes per wave and row), then issues its row
+    // loads; nothing waits on a value of L until all four rows are in flight.
     const double* zero = reinterpret_cast<const double*>(lmask) - 1;   // the word in front of the masks holds 0
     const int64_t zoff = zero - L;                                     // (flat global address space)
     unsigned nzbits[4];
@@ -1572,14 +1573,9 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
     for (int r = 0; r < 4; ++r) { g[r] = strip4_node(N, r, H, pxy); nzbits[r] = 0x3fu; }
     // order of issue: the mask words, then the 12 loads that do not depend on them (diagonal, b, x), and only then
     // -- after waiting for the (older) mask loads alone -- the 24 masked loads of L: the mask round trip is covered
-    unsigned long long mw[4][W - 1];
     if (lmask) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {      // all 12 (16-byte) mask loads first: one round trip, not four
-            const unsigned long long* src = lmask + ((int64_t)bz * nwords + (g[r].i >> 6)) * (W - 1);
-#pragma unroll
-            for (int s = 0; s < W - 1; ++s) mw[r][s] = src[s];
-        }
+        for (int r = 0; r < 4; ++r) nzbits[r] = lmask[voff + g[r].i];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1587,15 +1583,6 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
         dg[r] = L[i];
         bv[r] = b_[voff + i];
         x[r] = xin[i];
-    }
-    if (lmask) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int s = 0; s < W - 1; ++s) bits |= (unsigned)((mw[r][s] >> (g[r].i & 63)) & 1ull) << s;
-            nzbits[r] = bits;
-        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1663,6 +1650,173 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
         if (MODE == 1) bigpart[(int64_t)bz * nwg + wg] = rmax;
         else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
     }
+}
+
+// The bandwidth-regime Jacobi launch as a WALK: `gridDim.x` persistent workgroups per batch member, each taking a
+// contiguous run of the patches in column-major order (down a column of patches, then the next column).  Vertically
+// adjacent patches share 2H of their 64 rows; the walker keeps the scaled rows (six off-diagonals, diagonal, b, input
+// iterate) of those rows in LDS when it steps down, so that they are fetched from memory once instead of twice: the
+// halo re-read remains in x only, (64/T) instead of (64/T)^2 of the matrix per launch.  The carried values are the
+// registers the previous patch computed from the same addresses with the same expressions: results are those of
+// k_strip4_jacobi<0> bit for bit.  Residual partials: one per walker (max over its patches).
+constexpr int WALK_CARRY_ROWS = 20;     // 2 * H, H <= 10
+__global__ void __launch_bounds__(STRIP_T)
+k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
+                     double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
+                     int g_build, double rel_tol, int H, int stagger, const uint8_t* __restrict__ lmask,
+                     int npy, int npatch, int carry_on) {
+    constexpr int W = 7;
+    __shared__ double top[2][16][64], bot[2][16][64];
+    __shared__ double carry[WALK_CARRY_ROWS][W + 2][64];
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    stagger_first_round(stagger);
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    double bnorm;
+    if (launch == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        if (wg == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rprev = reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        if (rprev <= rel_tol * bnorm) {
+            if (wg == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
+                ctl->resid = bnorm > 0.0 ? rprev / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
+    double* xout = ((launch & 1) ? xa_ : xb_) + voff;
+    const int st = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double* zero = reinterpret_cast<const double*>(lmask) - 1;   // the word in front of the masks holds 0
+    const int64_t zoff = zero - L;
+    const int T = T4_L - 2 * H;
+    const int q0 = (int)((int64_t)wg * npatch / nwg), q1 = (int)((int64_t)(wg + 1) * npatch / nwg);
+    double rmax = 0.0;
+    unsigned nznext = 0;
+    const int lx0 = threadIdx.x & 63;
+    for (int q = q0; q < q1; ++q) {
+        // the lane index is made opaque per patch: otherwise the ~20 LDS / global addresses derived from it are hoisted
+        // out of the walk as loop invariants and spilled -- and a spill in the load phase waits on a load (vmcnt is one
+        // in-order queue), which serialises the mask and row round trips
+        int lx = lx0;
+        asm volatile("" : "+v"(lx));
+        const int px = q / npy, py = q - px * npy;
+        const bool cin = carry_on && q > q0 && py > 0;           // the previous patch of this walker is the one below in y
+        const bool cout = carry_on && q + 1 < q1 && py + 1 < npy;
+        const unsigned pxy = (unsigned)px | ((unsigned)py << 16);
+        Strip4Node g[4];
+        double lv[4][W - 1], dg[4], bv[4], x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[r] = strip4_node(N, r, H, pxy, lx, st);
+        // a wave takes its four rows either all from the carry or all from memory (for H = 9 the wave that straddles
+        // row 2H re-reads two rows: 3 % of the patch)
+        if (cin && 4 * st + 3 < 2 * H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * st + r;
+#pragma unroll
+                for (int s = 0; s < W - 1; ++s) lv[r][s] = carry[c][s][lx];
+                dg[r] = carry[c][W - 1][lx];
+                bv[r] = carry[c][W][lx];
+                x[r] = carry[c][W + 1][lx];
+            }
+        } else {
+            // the four mask bytes first, then all 36 loads of the four rows at once
+            unsigned nzbits[4] = {0x3fu, 0x3fu, 0x3fu, 0x3fu};
+            if (lmask) {
+                if (q > q0) {          // fetched during the previous patch's sweeps
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nzbits[r] = (nznext >> (8 * r)) & 0xffu;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nzbits[r] = lmask[voff + g[r].i];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = g[r].i;
+                dg[r] = L[i];
+                bv[r] = b_[voff + i];
+                x[r] = xin[i];
+#pragma unroll
+                for (int s = 1; s < W; ++s) {
+                    const int64_t off = ((nzbits[r] >> (s - 1)) & 1u) ? (int64_t)s * n + i : zoff;
+                    lv[r][s - 1] = L[off];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double rdg = 1.0 / dg[r];
+#pragma unroll
+                for (int s = 0; s < W - 1; ++s) lv[r][s] = g[r].inside ? lv[r][s] * rdg : 0.0;
+                bv[r] = g[r].inside ? bv[r] * rdg : 0.0;
+                x[r] = g[r].inside ? x[r] : 0.0;
+                dg[r] = g[r].inside ? dg[r] : 1.0;
+            }
+        }
+        __syncthreads();                   // carry consumed; the previous patch's last sweep has left top / bot
+        if (cout) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * st + r - T;
+                if (c < 0) continue;
+#pragma unroll
+                for (int s = 0; s < W - 1; ++s) carry[c][s][lx] = lv[r][s];
+                carry[c][W - 1][lx] = dg[r];
+                carry[c][W][lx] = bv[r];
+                carry[c][W + 1][lx] = x[r];
+            }
+        }
+        // The next patch's mask bytes are requested before the sweeps: its 36 row loads can then go out right behind
+        // this patch's stores instead of waiting a round trip for the masks (which, vmcnt being one in-order queue,
+        // would itself wait for the stores to be acknowledged).
+        unsigned nzn[4] = {0, 0, 0, 0};
+        if (lmask && q + 1 < q1) {
+            const int qn = q + 1, pxn = qn / npy, pyn = qn - pxn * npy;
+            const unsigned pxyn = (unsigned)pxn | ((unsigned)pyn << 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nzn[r] = lmask[voff + strip4_node(N, r, H, pxyn, lx, st).i];
+        }
+        for (int k = 0; k < K; ++k) {
+            const int par = k & 1;
+            bot[par][st][lx] = x[0];
+            top[par][st][lx] = x[3];
+            __syncthreads();
+            const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+            const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+            STRIP4_NEIGHBOURS(x, above, below);
+            double xn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = bv[r];
+#pragma unroll
+                for (int s = 0; s < W - 1; ++s) acc = fma(-lv[r][s], STRIP4_NB(x, above, below, r, s), acc);
+                if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
+                xn[r] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = xn[r];
+        }
+        nznext = nzn[0] | (nzn[1] << 8) | (nzn[2] << 16) | (nzn[3] << 24);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g[r].owned) xout[g[r].i] = x[r];
+    }
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
 }
 
 __global__ void __launch_bounds__(STRIP_T)
@@ -1857,14 +2011,29 @@ int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
     return best_h;
 }
 
+// Walkers per batch member of the walking Jacobi launch (0: one workgroup per patch).  One 1024-thread workgroup fits
+// a CU, so a launch keeps num_cus of them busy: with at least two patches per walker the carried rows pay, below that
+// hardware dispatch of one workgroup per patch fills the chip better.
+int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch) {
+    if (!ctx->t4_walk || !ctx->t4_dpp || 2 * H > WALK_CARRY_ROWS) return 0;
+    const int t = femfct_tile4_tiles(ctx, H);
+    const int w = std::min(ctx->num_cus / std::max(1, (int)batch), FEMFCT_MAX_PARTIALS);
+    if (w < 1 || (int64_t)t * t < 2 * (int64_t)w) return 0;
+    return w;
+}
+
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
-                                int g_build, int32_t batch, int H, int K, int check_every, const unsigned long long* lmask) {
+                                int g_build, int32_t batch, int H, int K, int check_every, const uint8_t* lmask) {
     const int t = femfct_tile4_tiles(ctx, H);
     const bool big = (int64_t)t * t > FEMFCT_MAX_PARTIALS;
     dim3 grid(t, t, batch);
     const size_t lds = (size_t)2 * T4_BUF * 8;
     femfct_prof_begin(ctx, KC_JACOBI);
-    if (ctx->t4_dpp) {
+    const int walkers = check_every > 0 ? 0 : femfct_tile4_walkers(ctx, H, batch);
+    if (walkers > 0) {
+        hipLaunchKernelGGL(k_strip4_jacobi_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa,
+                           xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, ctx->t4_stagger, lmask, t, t * t, ctx->t4_walk == 1 ? 1 : 0);
+    } else if (ctx->t4_dpp) {
         if (big) {
             hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
                                ctx->d_ctl, launch, K, g_build, ctx->rel_tol, ctx->d_bigpart, H, check_every, (int64_t)t * t * batch >= 1024 ? ctx->t4_stagger : 0, lmask, ctx->t4_xcd);
