@@ -1959,6 +1959,111 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
         }
 }
 
+// k_strip4_cheb_mass with persistent workgroups (see k_strip4_jacobi_walk), each taking every gridDim.x-th patch.
+// No rows are carried (the inputs are three vectors, 24 bytes per node); what the walk buys here is that the next
+// patch's inputs are requested BEFORE the sweeps of the current one, so the ~10 sweeps cover their latency, and that no
+// workgroup start-up sits between two patches on a CU.
+__global__ void __launch_bounds__(STRIP_T)
+k_strip4_cheb_mass_walk(int n, int N, double h, const double* __restrict__ b_, const double* __restrict__ ymid_,
+                        const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
+                        CheOmegas om, double md_scale, int H, int npy, int npatch) {
+    __shared__ double top[2][16][64], bot[2][16][64];
+    const int64_t voff = (int64_t)blockIdx.z * n;
+    const int st = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nc = N - 1;
+    const double inv_scale = 1.0 / md_scale;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    // patches wg, wg + nwg, ...: patches on the mesh boundary (general stencil weights: slower sweeps) spread evenly
+    const int q0 = wg, q1 = npatch;
+    const int lx0 = threadIdx.x & 63;
+    double pb[4], pym[4], pyo[4];          // raw inputs of the patch about to be processed
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pb[r] = 0.0; pym[r] = 0.0; pyo[r] = 0.0; }
+    if (q0 < q1) {
+        const int px = q0 / npy, py = q0 - px * npy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = strip4_node(N, r, H, (unsigned)px | ((unsigned)py << 16), lx0, st).i;   // (outside lanes: node 0, discarded)
+            pb[r] = b_[voff + i];
+            if (ymid_) pym[r] = ymid_[voff + i];
+            if (yold_) pyo[r] = yold_[voff + i];
+        }
+    }
+    for (int q = q0; q < q1; q += nwg) {
+        int lx = lx0;
+        asm volatile("" : "+v"(lx));       // (keeps the addresses derived from the lane index out of the walk's invariants)
+        const int px = q / npy, py = q - px * npy;
+        Strip4Node g[4];
+        double bv[4], cw[4], ym[4], yo[4];
+        int pc[4];            // six 2-bit edge counts, slots E, NE, N, W, SW, S
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            g[r] = strip4_node(N, r, H, (unsigned)px | ((unsigned)py << 16), lx, st);
+            bv[r] = 0.0; cw[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0; pc[r] = 0;
+            if (g[r].inside) {
+                const int gy = g[r].i / N, gx = g[r].i - gy * N;
+                const int c00 = (gx < nc && gy < nc), c10 = (gx > 0 && gy < nc), c01 = (gx < nc && gy > 0), c11 = (gx > 0 && gy > 0);
+                const int ntri = 2 * c00 + c10 + c01 + 2 * c11;
+                pc[r] = (c00 + c01) | ((2 * c00) << 2) | ((c00 + c10) << 4) | ((c10 + c11) << 6) | ((2 * c11) << 8) | ((c11 + c01) << 10);
+                cw[r] = 1.0 / (2.0 * md_scale * ntri);
+                if (pc[r] == 0xAAA) cw[r] = 2.0 * cw[r];
+                bv[r] = pb[r] * (12.0 / (md_scale * ntri * h * h));
+                ym[r] = pym[r];
+                yo[r] = pyo[r];
+            }
+        }
+        if (q + nwg < q1) {
+            const int qn = q + nwg, pxn = qn / npy, pyn = qn - pxn * npy;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = strip4_node(N, r, H, (unsigned)pxn | ((unsigned)pyn << 16), lx, st).i;
+                pb[r] = b_[voff + i];
+                if (ymid_) pym[r] = ymid_[voff + i];
+                if (yold_) pyo[r] = yold_[voff + i];
+            }
+        }
+        const bool all_interior = __all(pc[0] == 0xAAA && pc[1] == 0xAAA && pc[2] == 0xAAA && pc[3] == 0xAAA);
+        __syncthreads();                   // the previous patch's last sweep has left top / bot
+#define CHEB_MASS_SWEEPS(INTERIOR)                                                                              \
+        for (int k = 0; k < K; ++k) {                                                                           \
+            const int par = k & 1;                                                                              \
+            bot[par][st][lx] = ym[0];                                                                           \
+            top[par][st][lx] = ym[3];                                                                           \
+            __syncthreads();                                                                                    \
+            const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;                                        \
+            const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;                                         \
+            STRIP4_NEIGHBOURS(ym, above, below);                                                                \
+            const double wk = om.w[k];                                                                          \
+            double yn[4];                                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                     \
+                double sum;                                                                                     \
+                int pcr = pc[r];                                                                                \
+                if (!(INTERIOR)) asm volatile("" : "+v"(pcr));                                                  \
+                if ((INTERIOR) || pcr == 0xAAA) {                                                               \
+                    sum = ((STRIP4_NB(ym, above, below, r, 0) + STRIP4_NB(ym, above, below, r, 1)) +            \
+                           (STRIP4_NB(ym, above, below, r, 2) + STRIP4_NB(ym, above, below, r, 3))) +           \
+                          (STRIP4_NB(ym, above, below, r, 4) + STRIP4_NB(ym, above, below, r, 5));              \
+                } else {                                                                                        \
+                    sum = 0.0;                                                                                  \
+                    _Pragma("unroll") for (int s = 0; s < 6; ++s)                                               \
+                        sum = fma((double)((pcr >> (2 * s)) & 3), STRIP4_NB(ym, above, below, r, s), sum);      \
+                }                                                                                               \
+                const double z = fma(-cw[r], sum, fma(-inv_scale, ym[r], bv[r]));                               \
+                yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];                                                       \
+            }                                                                                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }                     \
+        }
+        if (all_interior) { CHEB_MASS_SWEEPS(true) } else { CHEB_MASS_SWEEPS(false) }
+#undef CHEB_MASS_SWEEPS
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g[r].owned) {
+                omid_[voff + g[r].i] = ym[r];
+                if (oold_) oold_[voff + g[r].i] = yo[r];
+            }
+    }
+}
+
 }  // namespace
 
 int femfct_tile4_init(femfct_ctx* ctx) {
@@ -2070,6 +2175,7 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
     const int H = single ? T4_H : femfct_tile4_halo(ctx, k_last - k_first + 1);
     const int per_launch = single ? ((io_in && io_in->om_dev) ? k_last - k_first + 1 : 24) : H;   // by-value omega table: 24
     const int t = femfct_tile4_tiles(ctx, H);
+    const int walkers = single ? 0 : femfct_tile4_walkers(ctx, H, batch);
     const size_t lds = (size_t)3 * T4_BUF * 8;
     const double* mid = in_mid;
     const double* old = in_old;
@@ -2086,7 +2192,10 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
-        if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in)
+        if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && walkers > 0)
+            hipLaunchKernelGGL(k_strip4_cheb_mass_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
+                               ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, t, t * t);
+        else if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in)
             hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
                                mid, old, omid, oold, k1 - k0, om, md_scale, H, ctx->t4_xcd);
         else if (ctx->t4_dpp)
