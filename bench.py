@@ -68,7 +68,7 @@ def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False,
     b = {
         "assemble": 7 * 8 * 3 + 6 * 4 + 8,          # Ad, Arot, A(write), neighbour indices, c   (per level)
         "build_low": 7 * 8 + l_bytes + d_bytes + 8 * 4,     # A, L(w), D(w), ml, u_n, b(w), x0(w)
-        "jacobi": l_bytes + 8 * 3,                  # L, b, x_in, x_out(w)
+        "jacobi": l_bytes + 8 * 3 + (1 if l_nonzero < 1.0 else 0),   # L, b, x_in, x_out(w), zero mask
         "dudt_rhs": 7 * 8 + 8 * 5,                  # A, u_L, M_diag, r(w), u_L copy(w), y1(w)
     }
     if inline_ops:                                  # operator derived in the kernels from Arot + the control's 1-ring
@@ -499,7 +499,9 @@ def roofline(hp, solvers, n_cells, steps, device_id):
                         if "traffic_bytes_per_launch" in e) / steps) if traffic else None
     dom_name = max(("jacobi", "cheb"), key=lambda k: kernels[k]["total_ms"])
     dom = kernels[dom_name]
-    sym = {3: {"jacobi": "k_strip4_jacobi<0>", "cheb": "k_strip4_cheb_mass" if geom else "k_strip4_cheb"},
+    walkers = ctx.patch_walkers(1, sweeps // max(1, steps)) if regime == 3 else 0
+    sym = {3: {"jacobi": "k_strip4_jacobi_walk" if walkers else "k_strip4_jacobi<0>",
+               "cheb": ("k_strip4_cheb_mass_walk" if walkers else "k_strip4_cheb_mass") if geom else "k_strip4_cheb"},
            2: {"jacobi": "k_tile_jacobi<H,0,BIG>", "cheb": "k_tile_cheb<H>"},
            1: {"jacobi": "k_strip_jacobi<RPT>", "cheb": "k_strip_cheb<RPT>"},
            0: {"jacobi": "k_jacobi<7,256,1>", "cheb": "k_cheb<7,256,1>"}}[regime][dom_name]
@@ -516,7 +518,7 @@ def roofline(hp, solvers, n_cells, steps, device_id):
                          "launch time by HIP events; frac = achieved / 8 TB/s",
            "workload": f"synthetic square mesh {n_cells + 1}x{n_cells + 1} (n={n}), vertex order, same CFL as C2",
            "compulsory_bytes_per_launch": dom["compulsory_bytes_per_row_per_launch"] * n,
-           "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "source_sha16": sha,
+           "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "patch_walkers": walkers, "source_sha16": sha,
            "operator": "derived inside k_build_low_sb / k_dudt_rhs_sb" if inline_ops else "stored by k_ops_solidbody",
            "low_order_offdiag_nonzero_fraction": l_nonzero, "d_stored_once_per_edge": half_d,
            "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms, "jacobi_sweeps_per_step": sweeps / steps,

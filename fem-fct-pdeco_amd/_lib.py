@@ -18,7 +18,7 @@ FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV = 1, 
 ORDER_VERTEX, ORDER_FENICS = 0, 1
 SOLVER_JACOBI, SOLVER_BICGSTAB = 0, 1
 REGIME_ROWS, REGIME_STRIPS, REGIME_TILE32, REGIME_PATCH64 = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FemFctError(RuntimeError):
@@ -73,6 +73,7 @@ SIGNATURES = {
     "femfct_set_graphs": (C.c_int, [_p, C.c_int]),
     "femfct_set_fusion": (C.c_int, [_p, C.c_int, C.c_int]),
     "femfct_kernel_regime": (C.c_int, [_p, _i]),
+    "femfct_patch_walkers": (C.c_int, [_p, _i, _i]),
     "femfct_lowop_nonzero_fraction": (C.c_int, [_p, _dp]),
     "femfct_set_profiling": (C.c_int, [_p, C.c_int]),
     "femfct_profile_report": (C.c_int, [_p, _p, _p, _i]),

@@ -253,6 +253,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_LMASK")) ctx->l_mask = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_XCD")) ctx->t4_xcd = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_WALK")) ctx->t4_walk = atoi(e);   // 2: walk without the carry (measurement)
+    if (const char* e = getenv("FEMFCT_T4_WALKERS")) { int v = atoi(e); if (v > 0) ctx->num_cus = v; }   // tests: walks on small meshes
     if (const char* e = getenv("FEMFCT_INLINE_OPS")) ctx->inline_ops = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_HALF_D")) ctx->half_d = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_STAGGER_US")) {
@@ -381,6 +382,11 @@ int femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch) {
     StripPlan sp;
     if (femfct_strip_plan(ctx, &sp)) return FEMFCT_REGIME_STRIPS;
     return FEMFCT_REGIME_ROWS;
+}
+
+int femfct_patch_walkers(const femfct_ctx* ctx, int32_t batch, int32_t sweeps) {
+    if (!ctx || ctx->n <= 0 || batch < 1 || !femfct_tile4_wanted(ctx, batch) || femfct_single_patch(ctx, batch)) return 0;
+    return femfct_tile4_walkers(ctx, femfct_tile4_halo(ctx, sweeps > 0 ? sweeps : 36), batch);
 }
 
 // Share of the off-diagonal entries of the most recent low-order operator (batch member 0) that are non-zero, i.e.

@@ -140,6 +140,11 @@ class Context:
     def set_fusion(self, strips=True, tiles=True):
         check(self.handle, lib.femfct_set_fusion(self.handle, int(bool(strips)), int(bool(tiles))))
 
+    def patch_walkers(self, batch=1, sweeps=36) -> int:
+        """Persistent workgroups per batch member of the bandwidth-regime Jacobi / Chebyshev launches (0: one
+        workgroup per patch)."""
+        return lib.femfct_patch_walkers(self.handle, int(batch), int(sweeps))
+
     def kernel_regime(self, batch=1) -> int:
         """_lib.REGIME_*: the Jacobi / Chebyshev kernel family a step with ``batch`` members runs."""
         return lib.femfct_kernel_regime(self.handle, int(batch))

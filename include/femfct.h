@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FEMFCT_ABI_VERSION 3   /* 3: femfct_kernel_regime, femfct_lowop_nonzero_fraction, femfct_chebsi_md, femfct_schnak_*_tw; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
+#define FEMFCT_ABI_VERSION 4   /* 4: femfct_patch_walkers; 3: femfct_kernel_regime, femfct_lowop_nonzero_fraction, femfct_chebsi_md, femfct_schnak_*_tw; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
 
 typedef struct femfct_ctx femfct_ctx;
 
@@ -93,6 +93,11 @@ int         femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles);
 #define FEMFCT_REGIME_TILE32  2   /* 32 x 32-patch tiles, latency regime (structured mesh, vertex order) */
 #define FEMFCT_REGIME_PATCH64 3   /* 64 x 64-patch register/DPP kernels, bandwidth regime (n * batch >= 90 000) */
 int         femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch);
+/* bandwidth regime: persistent workgroups per batch member of the Jacobi / Chebyshev launches for a solve of `sweeps`
+ * sweeps (each walks over its share of the 64 x 64 patches; the Jacobi walkers carry the rows two vertically adjacent
+ * patches share in LDS); 0 = one workgroup per patch (fewer than two patches per compute unit, other regimes,
+ * FEMFCT_T4_WALK=0).  Diagnostic. */
+int         femfct_patch_walkers(const femfct_ctx* ctx, int32_t batch, int32_t sweeps);
 /* share of the off-diagonal entries of the most recent low-order operator L = M_L + dt (A - D + N) that are non-zero
  * (an upwind stencil: about one half for pure convection).  In the bandwidth regime the Jacobi launches neither store
  * nor load the vanishing ones; 1.0 when that shortcut is not in use.  Diagnostic; synchronises. */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 40
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.femfct_abi_version() == 3
+    assert lib.femfct_abi_version() == 4
 
 
 def test_python_binding_covers_header():

@@ -12,6 +12,7 @@ Tolerance: relative l2 error per trajectory < 1e-6 (north star); the measured er
 expected around 1e-11.  Mass and bounds are checked where the scheme guarantees them.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -188,13 +189,17 @@ def test_c4_chemotaxis_41x41_200_steps_forward_adjoint(hp):
     assert abs(ug.min() - uo.min()) < 1e-9 and abs(ug.max() - uo.max()) < 1e-9 and abs(vg.min() - vo.min()) < 1e-9
 
 
-@pytest.mark.parametrize("nc", [330, 511])
-def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
+@pytest.mark.parametrize("nc,walkers", [(330, 0), (511, 0), (330, 7), (511, 10)])
+def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc, walkers, monkeypatch):
     """n >= 90 000 selects the 64 x 64-patch kernels (k_strip4_jacobi / k_strip4_cheb[_mass] and the fused
     limiter); here they face the CPU oracle directly (not only the one-sweep GPU kernels): 2 forward + 2 adjoint
-    steps at 331^2 (partial edge patches) and 512^2 nodes."""
+    steps at 331^2 (partial edge patches) and 512^2 nodes.  walkers > 0: the persistent-workgroup variants
+    (k_strip4_jacobi_walk with its LDS row carry, k_strip4_cheb_mass_walk), which a mesh selects by itself only from
+    two patches per compute unit on (~ 1000^2 nodes): here 7 / 10 walkers over 64 / 144 patches, runs that cross
+    column ends."""
     from oracle import traj as otraj
     Nt = 2
+    monkeypatch.setenv("FEMFCT_T4_WALKERS", str(walkers) if walkers else "100000")
     omesh, asm = _oracle(-1.0, 1.0, nc)
     n = omesh.nodes
     dt = 1e-3 * (2.0 / nc) / 0.025                      # the CFL number of C2
@@ -220,6 +225,8 @@ def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
     try:
         if _fusion_knobs_on():           # (a tuning knob may have switched the fused kernels off: then the row kernels face the oracle)
             assert prob.ctx.uses_bandwidth_tiles(1), "this size must select the 64-patch kernels"
+            if os.environ.get("FEMFCT_T4_WALK", "1") == "1" and os.environ.get("FEMFCT_T4_DPP", "1") != "0":
+                assert prob.ctx.patch_walkers(1) == walkers
         uk = np.zeros((Nt + 1) * n)
         uk[:n] = u0
         prob.solve_state(c, uk)
@@ -233,7 +240,7 @@ def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc):
 
 
 def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch):
-    """Three traffic savers of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
+    """Four shortcuts of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
     operator derived inside k_build_low_sb / k_dudt_rhs_sb instead of stored by k_ops_solidbody and read back;
     (ii) FEMFCT_LMASK -- the exactly-zero off-diagonals of the upwind low-order operator neither stored nor loaded
     by the Jacobi patches; (iii) FEMFCT_HALF_D -- d_ij stored once per edge, the limiter takes d_ji from the
@@ -248,10 +255,15 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
     c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1) + 0.1 * rng.random((Nt + 1) * n)
     for eps in (0.0, 1e-3):
         outs = []
-        for inline_ops, lmask, half_d in (("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "0", "1"), ("1", "1", "1")):
+        # (iv) FEMFCT_T4_WALKERS -- the persistent-workgroup launches (Jacobi with the LDS row carry, Chebyshev with
+        # the look-ahead loads), forced onto this small mesh with 5 / 9 walkers, with and without the zero mask
+        for inline_ops, lmask, half_d, walkers in (("0", "0", "0", "100000"), ("1", "0", "0", "100000"), ("0", "1", "0", "100000"),
+                                                   ("0", "0", "1", "100000"), ("1", "1", "1", "100000"),
+                                                   ("0", "0", "0", "5"), ("1", "1", "1", "9")):
             monkeypatch.setenv("FEMFCT_INLINE_OPS", inline_ops)
             monkeypatch.setenv("FEMFCT_LMASK", lmask)
             monkeypatch.setenv("FEMFCT_HALF_D", half_d)
+            monkeypatch.setenv("FEMFCT_T4_WALKERS", walkers)
             prob = solvers.SolidBodyDrift(mesh, Nt, dt, eps=eps, order=hp.ORDER_VERTEX)
             try:
                 if _fusion_knobs_on():

@@ -19,7 +19,7 @@ import sys
 
 # kernel -> class, separately for the product path at the roofline size (fused multi-sweep kernels, operator derived
 # in the kernels) and for the fusions-off pass of bench.py (one-sweep kernels); both run in the same bench.py process
-PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_dudt_rhs_sb": "dudt_rhs", "k_strip4_cheb_mass": "cheb",
+PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_strip4_jacobi_walk": "jacobi", "k_strip4_cheb_mass_walk": "cheb", "k_dudt_rhs_sb": "dudt_rhs", "k_strip4_cheb_mass": "cheb",
            "k_strip4_cheb": "cheb", "k_tile_flux_limit": "flux", "k_tile_jacobi": "jacobi", "k_tile_cheb": "cheb",
            "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb"}
 ONE_SWEEP = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_dudt_rhs": "dudt_rhs", "k_cheb": "cheb", "k_flux": "flux",
@@ -37,7 +37,8 @@ def load(path, counter, min_grid):
             m = re.search(r"\bk_[a-z_0-9]+", r["Kernel_Name"])
             if not m:
                 continue
-            large = "<7, 256" in r["Kernel_Name"] or int(r["Grid_Size"]) >= min_grid
+            # (the walking kernels run one persistent workgroup per CU and exist only on large meshes)
+            large = "<7, 256" in r["Kernel_Name"] or int(r["Grid_Size"]) >= min_grid or m.group(0).endswith("_walk")
             if large:
                 agg[m.group(0)].append(float(r["Counter_Value"]))
     return agg
