@@ -39,9 +39,10 @@ __device__ __forceinline__ double row_from_prev(double v) {
 
 // SHIFT: 0 none (uses own value), 1 wave_shl/shr DPP, 2 row_shl/shr DPP, 3 ds_bpermute
 // LDSX: 0 no LDS/barrier, 1 LDS rows + barrier (product), 2 barrier only
-template <int SHIFT, int LDSX, int ROWS, int ORDER = 0>
-__global__ void __launch_bounds__(64 * (64 / ROWS)) k_sweeps(const double* __restrict__ in, double* __restrict__ out, int K) {
-    constexpr int NS = 64 / ROWS;   // strips (waves) per workgroup: the patch is always 64 x 64
+// PH: patch height (64: the product's patch; 32 with ROWS = 4: 512-thread workgroups, two of which fit a CU)
+template <int SHIFT, int LDSX, int ROWS, int ORDER = 0, int PH = 64>
+__global__ void __launch_bounds__(64 * (PH / ROWS)) k_sweeps(const double* __restrict__ in, double* __restrict__ out, int K) {
+    constexpr int NS = PH / ROWS;   // strips (waves) per workgroup
     __shared__ double top[2][NS][64], bot[2][NS][64];
     const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
     double lv[ROWS][6], bv[ROWS], x[ROWS];
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(64 * (64 / ROWS)) k_sweeps(const double* __res
     for (int r = 0; r < ROWS; ++r) out[base + r] = x[r];
 }
 
-template <int SHIFT, int LDSX, int ROWS, int ORDER = 0>
+template <int SHIFT, int LDSX, int ROWS, int ORDER = 0, int PH = 64>
 static void run(const char* name, const double* in, double* out, int wgs, int K) {
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -107,7 +108,7 @@ static void run(const char* name, const double* in, double* out, int wgs, int K)
         for (int pass = 0; pass < 2; ++pass) {
             const int kk = pass ? K : 0;
             CHECK(hipEventRecord(a, 0));
-            hipLaunchKernelGGL((k_sweeps<SHIFT, LDSX, ROWS, ORDER>), dim3(wgs), dim3(64 * (64 / ROWS)), 0, 0, in, out, kk);
+            hipLaunchKernelGGL((k_sweeps<SHIFT, LDSX, ROWS, ORDER, PH>), dim3(wgs * (64 / PH)), dim3(64 * (PH / ROWS)), 0, 0, in, out, kk);
             CHECK(hipEventRecord(b, 0));
             CHECK(hipEventSynchronize(b));
             float ms; CHECK(hipEventElapsedTime(&ms, a, b));
@@ -206,6 +207,8 @@ int main(int argc, char** argv) {
     run<1, 1, 8, 1>("8 rows per thread, 8 waves, inner rows first", in, out, wgs, K);
     run<1, 0, 8, 0>("8 rows per thread, no LDS / barrier", in, out, wgs, K);
     run<1, 1, 16, 1>("16 rows per thread, 4 waves, inner first", in, out, wgs, K);
+    run<1, 1, 4, 0, 32>("64 x 32 patches, 8 waves, 2 workgroups per CU (time per PAIR)", in, out, wgs, K);
+    run<1, 1, 4, 1, 32>("64 x 32 patches, 8 waves, inner rows first (per pair)", in, out, wgs, K);
     run_cheb<0>("Chebyshev sweep, product expression order", in, out, wgs, K);
     run_cheb<1>("Chebyshev sweep, short dependent chains", in, out, wgs, K);
     return 0;
