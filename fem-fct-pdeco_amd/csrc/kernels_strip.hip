@@ -1664,7 +1664,7 @@ __global__ void __launch_bounds__(STRIP_T)
 k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                      double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
                      int g_build, double rel_tol, int H, int stagger, const uint8_t* __restrict__ lmask,
-                     int npy, int npatch, int carry_on) {
+                     int npy, int npatch, int carry_on, int up) {
     constexpr int W = 7;
     __shared__ double top[2][16][64], bot[2][16][64];
     __shared__ double carry[WALK_CARRY_ROWS][W + 2][64];
@@ -1707,15 +1707,20 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
     double rmax = 0.0;
     unsigned nznext = 0;
     const int lx0 = threadIdx.x & 63;
-    for (int q = q0; q < q1; ++q) {
+    // up: the run is walked backwards (up the columns).  Successive launches of a solve alternate the direction, so that a
+    // launch starts on the rows the previous one touched last: what of the matrix is still in the Infinity Cache is hit
+    // before it is evicted (a cyclic sweep over more than the cache holds would otherwise miss every time).
+    for (int j = 0; j < q1 - q0; ++j) {
+        const int q = up ? q1 - 1 - j : q0 + j;
         // the lane index is made opaque per patch: otherwise the ~20 LDS / global addresses derived from it are hoisted
         // out of the walk as loop invariants and spilled -- and a spill in the load phase waits on a load (vmcnt is one
         // in-order queue), which serialises the mask and row round trips
         int lx = lx0;
         asm volatile("" : "+v"(lx));
         const int px = q / npy, py = q - px * npy;
-        const bool cin = carry_on && q > q0 && py > 0;           // the previous patch of this walker is the one below in y
-        const bool cout = carry_on && q + 1 < q1 && py + 1 < npy;
+        // the previous / next patch of this walker is the vertical neighbour (not across a column end)
+        const bool cin = carry_on && j > 0 && (up ? py + 1 < npy : py > 0);
+        const bool cout = carry_on && j + 1 < q1 - q0 && (up ? py > 0 : py + 1 < npy);
         const unsigned pxy = (unsigned)px | ((unsigned)py << 16);
         Strip4Node g[4];
         double lv[4][W - 1], dg[4], bv[4], x[4];
@@ -1723,10 +1728,10 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
         for (int r = 0; r < 4; ++r) g[r] = strip4_node(N, r, H, pxy, lx, st);
         // a wave takes its four rows either all from the carry or all from memory (for H = 9 the wave that straddles
         // row 2H re-reads two rows: 3 % of the patch)
-        if (cin && 4 * st + 3 < 2 * H) {
+        if (cin && (up ? 4 * st >= T : 4 * st + 3 < 2 * H)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 4 * st + r;
+                const int c = 4 * st + r - (up ? T : 0);
 #pragma unroll
                 for (int s = 0; s < W - 1; ++s) lv[r][s] = carry[c][s][lx];
                 dg[r] = carry[c][W - 1][lx];
@@ -1737,7 +1742,7 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
             // the four mask bytes first, then all 36 loads of the four rows at once
             unsigned nzbits[4] = {0x3fu, 0x3fu, 0x3fu, 0x3fu};
             if (lmask) {
-                if (q > q0) {          // fetched during the previous patch's sweeps
+                if (j > 0) {           // fetched during the previous patch's sweeps
 #pragma unroll
                     for (int r = 0; r < 4; ++r) nzbits[r] = (nznext >> (8 * r)) & 0xffu;
                 } else {
@@ -1771,8 +1776,8 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
         if (cout) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 4 * st + r - T;
-                if (c < 0) continue;
+                const int c = 4 * st + r - (up ? 0 : T);       // walking down the top 2H rows are kept, walking up the bottom ones
+                if (c < 0 || c >= 2 * H) continue;
 #pragma unroll
                 for (int s = 0; s < W - 1; ++s) carry[c][s][lx] = lv[r][s];
                 carry[c][W - 1][lx] = dg[r];
@@ -1784,8 +1789,8 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
         // this patch's stores instead of waiting a round trip for the masks (which, vmcnt being one in-order queue,
         // would itself wait for the stores to be acknowledged).
         unsigned nzn[4] = {0, 0, 0, 0};
-        if (lmask && q + 1 < q1) {
-            const int qn = q + 1, pxn = qn / npy, pyn = qn - pxn * npy;
+        if (lmask && j + 1 < q1 - q0) {
+            const int qn = up ? q - 1 : q + 1, pxn = qn / npy, pyn = qn - pxn * npy;
             const unsigned pxyn = (unsigned)pxn | ((unsigned)pyn << 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) nzn[r] = lmask[voff + strip4_node(N, r, H, pxyn, lx, st).i];
@@ -2137,7 +2142,7 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     const int walkers = check_every > 0 ? 0 : femfct_tile4_walkers(ctx, H, batch);
     if (walkers > 0) {
         hipLaunchKernelGGL(k_strip4_jacobi_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa,
-                           xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, ctx->t4_stagger, lmask, t, t * t, ctx->t4_walk == 1 ? 1 : 0);
+                           xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, ctx->t4_stagger, lmask, t, t * t, ctx->t4_walk == 1 ? 1 : 0, ctx->t4_snake ? (launch & 1) : 0);
     } else if (ctx->t4_dpp) {
         if (big) {
             hipLaunchKernelGGL(k_strip4_jacobi<1>, grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, xb, ctx->d_part,
