@@ -78,6 +78,7 @@ struct femfct_ctx {
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int t4_snake = 1;           // walking Jacobi launches alternate their direction (FEMFCT_T4_SNAKE)
+    int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
     int t4_walk = 1;            // 64-patch Jacobi: persistent workgroups walk down columns of patches, shared rows carried in LDS (FEMFCT_T4_WALK)
     int num_cus = 256;          // compute units of the device (one 1024-thread walker each)
     int t4_xcd = 0;             // 64-patch kernels: x-neighbouring patches under the same XCD's L2 (FEMFCT_T4_XCD)
@@ -217,7 +218,7 @@ int femfct_enqueue_strip_cheb(femfct_ctx* ctx, const StripPlan& pl, const double
 struct TilePlan { int tiles, K, H; };
 bool femfct_tile_plan(const femfct_ctx* ctx, TilePlan* pl, bool need_partials = true, int budget = 0, int batch = 1);
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
-                               double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch = 0);
+                               double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch = 0, int defer = 0);
 int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, struct MatRef A, const double* Nm, int32_t nshared,
                                      struct VecRef rhs, int64_t rhs_bstride, struct VecRef u_n, int64_t u_bstride, double dt,
                                      int32_t batch);

@@ -355,7 +355,8 @@ template <int H, int EXACT, int BIG>
 __global__ void __launch_bounds__(STRIP_T)
 k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
               double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
-              int g_build, double rel_tol, double* __restrict__ bigpart, double* __restrict__ partk, int bn_launch) {
+              int g_build, double rel_tol, double* __restrict__ bigpart, double* __restrict__ partk, int bn_launch,
+              int defer) {
     constexpr int W = 7;
     __shared__ double xs[2][TILE_L * TILE_LD];
     __shared__ double smem[96];
@@ -370,7 +371,12 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     // residual the previous launch left.  In the fused case all three come out of one reduction pass.
     double rmax_prev = 0.0;
     bool have_rmax = false;
-    if (launch == bn_launch) {
+    // defer: second and last launch of a solve whose first launch built the operator -- nothing is reduced and nothing
+    // tested here (the test of launch 0's residual practically never passes; waiting for its partials costs this launch
+    // ~2 us of its ~10); workgroup 0 of k_tile_dudt_cheb reduces everything at once (solve_ctl.h, deferred_test_*)
+    if (defer) {
+        bnorm = 0.0;
+    } else if (launch == bn_launch) {
         double rsmin = INFINITY;
         bnorm = 0.0;
         if (!BIG && launch > 0 && g_build == nwg) {
@@ -394,7 +400,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     } else {
         bnorm = ctl->bnorm;
     }
-    if (launch > 0) {
+    if (launch > 0 && !defer) {
         double rmax = have_rmax ? rmax_prev
                       : BIG   ? ctl->rs[(launch - 1) & 1]
                               : reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
@@ -1042,7 +1048,7 @@ int femfct_enqueue_tile_build_jacobi(femfct_ctx* ctx, const TilePlan& pl, MatRef
 }
 
 int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double* L, const double* b, double* xa,
-                               double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch) {
+                               double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch, int defer) {
     const bool big = femfct_tile_big(ctx, pl);
     double* bigp = big ? ctx->d_bigpart : nullptr;
     double* pk = (last && !big) ? ctx->d_partk : nullptr;
@@ -1051,11 +1057,11 @@ int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double
 #define TJ(HH)                                                                                                          \
     do {                                                                                                                \
         if (big) hipLaunchKernelGGL((k_tile_jacobi<8, 0, 1>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,  \
-                                    xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch); \
+                                    xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch, 0); \
         else if (pk) hipLaunchKernelGGL((k_tile_jacobi<HH, 1, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, \
-                                        b, xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch); \
+                                        b, xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch, 0); \
         else hipLaunchKernelGGL((k_tile_jacobi<HH, 0, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, \
-                                xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch); \
+                                xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch, defer); \
     } while (0)
     switch (pl.H) {
         case 8: TJ(8); break; case 9: TJ(9); break; case 10: TJ(10); break;
@@ -1123,14 +1129,20 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
                  int K, CheOmegas om, double md_scale, double omega1) {
     constexpr int W = 7, H = 10;
     __shared__ double ys[3][TILE_L * TILE_LD];
-    __shared__ double smem[32];
+    __shared__ double smem[64];
     const int bz = blockIdx.z;
     StepCtl* ctl = ctl_ + bz;
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     const int parity = ctl->done ? ctl->parity : (budget & 1);
-    finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
-                   partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
+    // deferred test (exact_k < 0): nothing below depends on its outcome, only the step log does -- workgroup 0 alone
+    // reduces the partials, and after its own tile, so that nobody waits for them
+    DeferredPartials dp{0.0, 0.0, 0.0, INFINITY};
+    if (exact_k >= 0)
+        finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
+                       partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
+    else if (wg == 0 && !ctl->done)
+        dp = deferred_test_load(p, part_count);
     const int64_t voff = (int64_t)bz * n;
     const double* A = mat_ptr(A_ref, bz);
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -1190,6 +1202,7 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         omid_[voff + g.i] = ys[im][g.self];
         if (oold_) oold_[voff + g.i] = ys[io][g.self];
     }
+    if (exact_k < 0 && wg == 0 && !ctl->done) deferred_test_publish(ctl, dp, iters_per_unit, rel_tol, smem);
 }
 
 }  // namespace

@@ -297,3 +297,47 @@ def test_large_batch_uses_bandwidth_tiles_and_matches_single(hp, solvers):
         prob.solve_state(cks[b], uk)          # batch 1: latency-regime kernels
         assert rel(out[b], uk) < 1e-11
     prob.close()
+
+
+def test_deferred_residual_test_reproduces_the_in_launch_one(hp, solvers, monkeypatch):
+    """FEMFCT_DEFER_CHECK: in the latency regime a low-order solve of two launches no longer tests launch 0's residual
+    inside launch 1; workgroup 0 of the du/dt kernel reduces all partials at once (solve_ctl.h).  Same trajectories to the
+    bit, same per-step solver records (sweeps, relative residual, minimal row sum, flags), forward and adjoint,
+    both DoF orders; a batch of trajectories too."""
+    nc, Nt, dt = 80, 12, 4e-4
+    mesh = hp.SquareMeshP1(-1, 1, nc)
+    n = mesh.nodes
+    x, y = mesh.coordinates()
+    rng = np.random.default_rng(23)
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1)
+    for order, batch in ((hp.ORDER_VERTEX, 1), (hp.ORDER_FENICS, 1), (hp.ORDER_VERTEX, 3)):
+        res = []
+        for defer in ("0", "1"):
+            monkeypatch.setenv("FEMFCT_DEFER_CHECK", defer)
+            prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=batch, order=order)
+            try:
+                tl = (Nt + 1) * n
+                init = np.zeros((batch, tl))
+                init[:, :n] = u0 * (1.0 + 0.1 * np.arange(batch))[:, None]
+                d_c = prob.ctx.array(np.tile(c, batch))
+                d_u = prob.ctx.array(init.reshape(-1))
+                for _ in range(3):                       # the sweep budget settles at two launches
+                    prob.forward(d_c, d_u, batch=batch)
+                logf = {k: v.copy() for k, v in prob.solver_log(batch).items()}
+                uk = d_u.download()
+                d_p = prob.ctx.array(np.zeros(batch * tl))
+                d_uhat = prob.ctx.array(np.tile(0.9 * uk[:tl].reshape(Nt + 1, n)[-1] + 0.01, batch))
+                for _ in range(3):
+                    prob.adjoint(d_c, d_u, d_uhat, d_p, "finaltime", batch=batch)
+                loga = {k: v.copy() for k, v in prob.solver_log(batch).items()}
+                res.append((uk, d_p.download(), logf, loga))
+            finally:
+                prob.close()
+        (u0_, p0_, lf0, la0), (u1_, p1_, lf1, la1) = res
+        assert np.array_equal(u0_, u1_) and np.array_equal(p0_, p1_)
+        for a, b in ((lf0, lf1), (la0, la1)):
+            # two launches (the second budgeted one needed): the case the deferral covers
+            assert 13 < int(a["solver_iters"].max()) <= 26, a["solver_iters"].max()
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
