@@ -362,7 +362,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     __shared__ double smem[96];
     const int bz = blockIdx.z;
     StepCtl* ctl = ctl_ + bz;
-    if (ctl->done) return;
+    if (!defer && ctl->done) return;       // (defer: nothing sets `done` before this launch -- one dependent round trip less)
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
     double bnorm;
@@ -1134,14 +1134,15 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
     StepCtl* ctl = ctl_ + bz;
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    const int parity = ctl->done ? ctl->parity : (budget & 1);
-    // deferred test (exact_k < 0): nothing below depends on its outcome, only the step log does -- workgroup 0 alone
-    // reduces the partials, and after its own tile, so that nobody waits for them
+    // deferred test (exact_k < 0): no launch of the solve set `done`, the iterate is the budget-parity one; nothing below
+    // depends on the test's outcome, only the step log does -- workgroup 0 alone reduces the partials, requested here
+    // and consumed after its own tile, so that nobody waits for them (nor for a look at the control block)
+    const int parity = exact_k < 0 ? (budget & 1) : ctl->done ? ctl->parity : (budget & 1);
     DeferredPartials dp{0.0, 0.0, 0.0, INFINITY};
     if (exact_k >= 0)
         finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
                        partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
-    else if (wg == 0 && !ctl->done)
+    else if (wg == 0)
         dp = deferred_test_load(p, part_count);
     const int64_t voff = (int64_t)bz * n;
     const double* A = mat_ptr(A_ref, bz);
@@ -1202,7 +1203,7 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         omid_[voff + g.i] = ys[im][g.self];
         if (oold_) oold_[voff + g.i] = ys[io][g.self];
     }
-    if (exact_k < 0 && wg == 0 && !ctl->done) deferred_test_publish(ctl, dp, iters_per_unit, rel_tol, smem);
+    if (exact_k < 0 && wg == 0) deferred_test_publish(ctl, dp, iters_per_unit, rel_tol, smem);
 }
 
 }  // namespace
