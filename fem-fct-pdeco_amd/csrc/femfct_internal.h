@@ -129,6 +129,11 @@ struct femfct_ctx {
     int32_t* d_level = nullptr;                                     // [2]: current level, step ordinal
     StepCtl* d_log = nullptr;                                       // [tr_steps * tr_batch]
     unsigned* d_ticket = nullptr;                                   // last-block ticket of the fused step end
+    // graph-relative time levels: step r of a captured graph of R steps addresses level[0] + r * delta (+ its offsets) and
+    // logs at ordinal level[1] + r; only the graph's last step moves the device counters (by R * delta and R).  Set by
+    // femfct_run_graph_reps around every enqueue; outside it (0, 0, true, 1) reproduces one self-contained step.
+    int level_bias = 0, ord_bias = 0, rep_total = 1;
+    bool rep_last = true;
     int end_req_delta = 0;          // != 0: the next step's last kernel also logs + advances the level
     bool end_req_krylov = false, end_fused = false;
     std::vector<StepCtl> h_log;                                     // last trajectory's log

@@ -690,7 +690,9 @@ k_tile_cheb(int n, int N, const double* __restrict__ M, const double* __restrict
 // blocks to the per-step log and move the time-level counter -- saves the separate k_step_end launch
 struct EndArgs {
     int32_t* level;          // null: nothing to do
-    int delta;
+    int delta;               // what the LAST step of a graph adds to the time level (R * step); 0 for the other steps
+    int ord_adv;             // what it adds to the step ordinal (R); 0: not the last step -- log only
+    int ord_off;             // this step's position in its graph: it logs at ordinal level[1] + ord_off
     const StepCtl* ctl;
     StepCtl* log;
     const KrylovCtl* kctl;   // may be null
@@ -699,11 +701,24 @@ struct EndArgs {
     unsigned* ticket;
 };
 
-// End of a time step folded into the step's last kernel: the workgroup that draws the last ticket copies the
-// per-step solver records into the trajectory log and advances the device-side time level.  Every workgroup
-// has resolved its level-dependent addresses before it draws a ticket, so moving the level is safe.
+// End of a time step folded into the step's last kernel.  The device counters (time level, step ordinal) move once per
+// captured graph (femfct_run_graph_reps): every step but the last only has its solver records copied into the
+// trajectory log, by workgroup (0,0,0) at the START of the kernel (the records are final by then) -- no atomic, no
+// extra barrier, nothing at the kernel's end.  The last step keeps the ticket: the workgroup that draws the last one
+// logs and moves the counters for all R steps (every workgroup has resolved its level-dependent addresses before it
+// draws a ticket, so moving the level is safe).  Measured at C2: the per-step ticket cost 6 of 37 us.
+__device__ __forceinline__ void step_log_early(const EndArgs& e) {
+    if (!e.level || e.ord_adv != 0) return;
+    if (blockIdx.x | blockIdx.y | blockIdx.z) return;
+    const int ord = e.level[1] + e.ord_off;
+    for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
+        e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
+        if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
+    }
+}
+
 __device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
-    if (!e.level) return;
+    if (!e.level || e.ord_adv == 0) return;
     __shared__ int is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -712,7 +727,8 @@ __device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
     }
     __syncthreads();
     if (is_last) {
-        const int ord = e.level[1];
+        const int ord0 = e.level[1];
+        const int ord = ord0 + e.ord_off;
         for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
             e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
             if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
@@ -720,7 +736,7 @@ __device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
         __syncthreads();
         if (threadIdx.x == 0) {
             e.level[0] += e.delta;
-            e.level[1] = ord + 1;
+            e.level[1] = ord0 + e.ord_adv;
             *e.ticket = 0u;
         }
     }
@@ -760,6 +776,7 @@ k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const do
 #pragma unroll
         for (int s = 0; s < 3; ++s) sdf[s][g.self] = dfw[s];
     }
+    step_log_early(e);        // (behind this kernel's own loads: its round trip rides on theirs)
     su[g.self] = ui;
     sd[g.self] = dui;
     srp[g.self] = 1.0;
@@ -859,6 +876,7 @@ k_tile_cheb_flux_limit(int n, int N, double h, const double* __restrict__ M, con
         ui = ulow_[voff + g.i];
         mli = ml[g.i];
     }
+    step_log_early(e);        // (behind this kernel's own loads: its round trip rides on theirs)
     ys[0][g.self] = yo;
     ys[1][g.self] = ym;
     su[g.self] = ui;
@@ -944,7 +962,8 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
     EndArgs e;
     e.level = nullptr;
     if (fuse_end) {
-        e.level = ctx->d_level; e.delta = ctx->end_req_delta; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
+        e.level = ctx->d_level; e.delta = ctx->rep_last ? ctx->end_req_delta * ctx->rep_total : 0;
+        e.ord_adv = ctx->rep_last ? ctx->rep_total : 0; e.ord_off = ctx->ord_bias; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
         e.kctl = ctx->end_req_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr; e.klog = (KrylovCtl*)ctx->d_klog;
         e.batch = batch; e.ticket = ctx->d_ticket;
     }
@@ -967,7 +986,8 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
     EndArgs e;
     e.level = nullptr;
     if (fuse_end) {
-        e.level = ctx->d_level; e.delta = ctx->end_req_delta; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
+        e.level = ctx->d_level; e.delta = ctx->rep_last ? ctx->end_req_delta * ctx->rep_total : 0;
+        e.ord_adv = ctx->rep_last ? ctx->rep_total : 0; e.ord_off = ctx->ord_bias; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
         e.kctl = ctx->end_req_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr; e.klog = (KrylovCtl*)ctx->d_klog;
         e.batch = batch; e.ticket = ctx->d_ticket;
     }
@@ -1203,7 +1223,7 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         omid_[voff + g.i] = ys[im][g.self];
         if (oold_) oold_[voff + g.i] = ys[io][g.self];
     }
-    if (exact_k < 0 && wg == 0) deferred_test_publish(ctl, dp, iters_per_unit, rel_tol, smem);
+    if (exact_k < 0 && wg == 0) deferred_test_publish(ctl, dp, iters_per_unit, rel_tol);
 }
 
 }  // namespace

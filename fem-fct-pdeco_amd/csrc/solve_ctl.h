@@ -6,36 +6,31 @@
 
 // Deferred test of a two-launch solve (launch 0 = k_tile_build_jacobi, launch 1 = k_tile_jacobi with defer = 1): neither
 // Jacobi launch looked at a partial, so ||b||, the minimal row sum and the two residual maxima are all reduced by the
-// kernel behind them, in one pass and one barrier pair (smem >= 64 doubles), and the verdict a launch-1 test would have
+// kernel behind them, in one pass, and the verdict a launch-1 test would have
 // reached is reconstructed.  Split in two so that the caller (workgroup 0 of k_tile_dudt_cheb) can request the partials
 // before its tile work and publish after it.  What differs from the in-launch test: had launch 0 already converged,
 // launch 1 ran nevertheless (its sweeps only lower the residual further; the iterate returned is the budget-parity one).
 struct DeferredPartials { double r0, r1, bn, rs; };
 
+// (wave 0 of the calling workgroup only: no LDS, no barrier -- the publish is a handful of lane shifts at the kernel's end)
 __device__ __forceinline__ DeferredPartials deferred_test_load(const double* p, int G) {
     DeferredPartials d{0.0, 0.0, 0.0, INFINITY};
-    for (int k = threadIdx.x; k < G; k += blockDim.x) {
-        d.r0 = fmax(d.r0, p[k]);
-        d.r1 = fmax(d.r1, p[FEMFCT_MAX_PARTIALS + k]);
-        d.bn = fmax(d.bn, p[2 * FEMFCT_MAX_PARTIALS + k]);
-        d.rs = fmin(d.rs, p[3 * FEMFCT_MAX_PARTIALS + k]);
+    if (threadIdx.x < WAVE) {
+        for (int k = threadIdx.x; k < G; k += WAVE) {
+            d.r0 = fmax(d.r0, p[k]);
+            d.r1 = fmax(d.r1, p[FEMFCT_MAX_PARTIALS + k]);
+            d.bn = fmax(d.bn, p[2 * FEMFCT_MAX_PARTIALS + k]);
+            d.rs = fmin(d.rs, p[3 * FEMFCT_MAX_PARTIALS + k]);
+        }
     }
     return d;
 }
 
-__device__ __forceinline__ void deferred_test_publish(StepCtl* ctl, DeferredPartials d, int iters_per_unit, double rel_tol,
-                                                      double* smem) {
-    double r0 = wave_reduce(d.r0, OpMax()), r1 = wave_reduce(d.r1, OpMax());
-    double bn = wave_reduce(d.bn, OpMax()), rs = wave_reduce(d.rs, OpMin());
-    const int nw = (blockDim.x + WAVE - 1) / WAVE, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    __syncthreads();
-    if (lane == 0) { smem[wid] = r0; smem[16 + wid] = r1; smem[32 + wid] = bn; smem[48 + wid] = rs; }
-    __syncthreads();
+__device__ __forceinline__ void deferred_test_publish(StepCtl* ctl, DeferredPartials d, int iters_per_unit, double rel_tol) {
+    if (threadIdx.x >= WAVE) return;
+    const double r0 = wave_reduce(d.r0, OpMax()), r1 = wave_reduce(d.r1, OpMax());
+    const double bn = wave_reduce(d.bn, OpMax()), rs = wave_reduce(d.rs, OpMin());
     if (threadIdx.x == 0) {
-        r0 = 0.0; r1 = 0.0; bn = 0.0; rs = INFINITY;
-        for (int w = 0; w < nw; ++w) {
-            r0 = fmax(r0, smem[w]); r1 = fmax(r1, smem[16 + w]); bn = fmax(bn, smem[32 + w]); rs = fmin(rs, smem[48 + w]);
-        }
         ctl->bnorm = bn;
         ctl->min_rowsum = rs;
         if (!(rs > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;

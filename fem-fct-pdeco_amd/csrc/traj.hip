@@ -57,17 +57,18 @@ int femfct_enqueue_axpby(femfct_ctx* ctx, int64_t count, double alpha, const dou
 namespace {
 
 // end of a step: log the solver control blocks, then move the level counter
-__global__ void k_step_end(int32_t* level, int delta, const StepCtl* __restrict__ ctl, StepCtl* __restrict__ log,
-                           const KrylovCtl* __restrict__ kctl, KrylovCtl* __restrict__ klog, int batch) {
-    int ord = level[1];
+__global__ void k_step_end(int32_t* level, int delta, int ord_adv, int ord_off, const StepCtl* __restrict__ ctl,
+                           StepCtl* __restrict__ log, const KrylovCtl* __restrict__ kctl, KrylovCtl* __restrict__ klog,
+                           int batch) {
+    const int ord = level[1];
     for (int b = threadIdx.x; b < batch; b += blockDim.x) {
-        log[(int64_t)ord * batch + b] = ctl[b];
-        if (kctl) klog[(int64_t)ord * batch + b] = kctl[b];
+        log[(int64_t)(ord + ord_off) * batch + b] = ctl[b];
+        if (kctl) klog[(int64_t)(ord + ord_off) * batch + b] = kctl[b];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && ord_adv) {      // the last step of a graph moves the counters for all of its steps
         level[0] += delta;
-        level[1] = ord + 1;
+        level[1] = ord + ord_adv;
     }
 }
 
@@ -86,7 +87,8 @@ int femfct_enqueue_step_end(femfct_ctx* ctx, int delta, int32_t batch, bool with
         ctx->end_fused = false;
         return FEMFCT_OK;
     }
-    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, ctx->d_level, delta, ctx->d_ctl, ctx->d_log,
+    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, ctx->d_level, ctx->rep_last ? delta * ctx->rep_total : 0,
+                       ctx->rep_last ? ctx->rep_total : 0, ctx->ord_bias, ctx->d_ctl, ctx->d_log,
                        with_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr, (KrylovCtl*)ctx->d_klog, batch);
     return FEMFCT_OK;
 }
@@ -175,23 +177,24 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
                                  key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol),
                                  key_bits(pre ? Aall.base : nullptr), key_bits(src_traj), key_bits((int32_t)inl)};
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, +1, [&]() {
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
             MatRef A = Aall;
-            const SbOpArgs sb{Arot, ctx->d_Ad, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0, rot_scale, bx, by};
+            if (A.level) A.level_off += ctx->level_bias;
+            const SbOpArgs sb{Arot, ctx->d_Ad, lref(ctx, c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0, rot_scale, bx, by};
             if (!pre && !inl) {
-                femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
+                femfct_enqueue_ops_solidbody(ctx, Arot, lref(ctx, c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
                                              rot_scale, bx, by, ctx->d_trA, batch);
                 A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
             }
             VecRef rhs = make_ref(nullptr);
             if (src_traj) {
-                femfct_enqueue_mass_diff(ctx, make_ref(src_traj, lv, n, 1), tstride, make_ref(nullptr), 0, ctx->d_trRhs, batch);
+                femfct_enqueue_mass_diff(ctx, lref(ctx, src_traj, lv, n, 1), tstride, make_ref(nullptr), 0, ctx->d_trRhs, batch);
                 rhs = make_ref(ctx->d_trRhs);
             }
             femfct_request_fused_end(ctx, 1, false);
             int r = femfct_enqueue_step_op(ctx, A, inl ? &sb : nullptr, nullptr, 0, rhs, n,
-                                           make_ref(u_traj, lv, n, 0), tstride, dt, make_ref(u_traj, lv, n, 1),
+                                           lref(ctx, u_traj, lv, n, 0), tstride, dt, lref(ctx, u_traj, lv, n, 1),
                                            tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
             femfct_enqueue_step_end(ctx, 1, batch, false);
@@ -235,24 +238,25 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
                                  key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
                                  key_bits((int32_t)budget), key_bits(ctx->rel_tol), key_bits(pre ? Aall.base : nullptr),
                                  key_bits((int32_t)inl)};
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, -1, [&]() {
             // level counter = n: control c_n (finaltime.py:213), p_{n+1} -> p_n
             MatRef A = Aall;
-            const SbOpArgs sb{Arot, ctx->d_Ad, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0, rot_scale, bx, by};
+            if (A.level) A.level_off += ctx->level_bias;
+            const SbOpArgs sb{Arot, ctx->d_Ad, lref(ctx, c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0, rot_scale, bx, by};
             if (!pre && !inl) {
-                femfct_enqueue_ops_solidbody(ctx, Arot, make_ref(c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
+                femfct_enqueue_ops_solidbody(ctx, Arot, lref(ctx, c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
                                              rot_scale, bx, by, ctx->d_trA, batch);
                 A = MatRef{ctx->d_trA, nullptr, 0, 0, (int64_t)ctx->W * n};
             }
             VecRef rhs = make_ref(nullptr);
             if (alltime) {  // rhs = assemble((uhat_n - u_n) v dx)  (alltime.py:257)
-                femfct_enqueue_mass_diff(ctx, make_ref(uhat, lv, n, 0), tstride, make_ref(u_traj, lv, n, 0), tstride,
+                femfct_enqueue_mass_diff(ctx, lref(ctx, uhat, lv, n, 0), tstride, lref(ctx, u_traj, lv, n, 0), tstride,
                                          ctx->d_trRhs, batch);
                 rhs = make_ref(ctx->d_trRhs);
             }
             femfct_request_fused_end(ctx, -1, false);
-            int r = femfct_enqueue_step_op(ctx, A, inl ? &sb : nullptr, nullptr, 0, rhs, n, make_ref(p_traj, lv, n, 1), tstride,
-                                           dt, make_ref(p_traj, lv, n, 0), tstride, batch, budget);
+            int r = femfct_enqueue_step_op(ctx, A, inl ? &sb : nullptr, nullptr, 0, rhs, n, lref(ctx, p_traj, lv, n, 1), tstride,
+                                           dt, lref(ctx, p_traj, lv, n, 0), tstride, batch, budget);
             if (r != FEMFCT_OK) return r;
             femfct_enqueue_step_end(ctx, -1, batch, false);
             return FEMFCT_OK;

@@ -36,15 +36,28 @@ static inline int femfct_round_kry_budget(const femfct_ctx* ctx, int b) {
 
 // Captured graph holding `reps` consecutive, identical time steps (the time level is a device counter).
 template <class F>
-int femfct_run_graph_reps(femfct_ctx* ctx, femfct_ctx::GraphKey key, int reps, F&& enqueue_one) {
+int femfct_run_graph_reps(femfct_ctx* ctx, femfct_ctx::GraphKey key, int reps, int delta, F&& enqueue_one) {
     key.push_back(key_bits((int32_t)reps));
+    // delta: the time-level step of this kind of sweep (+1 forward, -1 adjoint).  Step r is enqueued with its level
+    // offset baked into every level-indirected reference (lref, MatRef::level_off); the device counters move once, in
+    // the last step of the graph -- no per-step ticket / counter update on the critical path of the other R - 1 steps.
+    struct Restore {
+        femfct_ctx* c;
+        ~Restore() { c->level_bias = 0; c->ord_bias = 0; c->rep_total = 1; c->rep_last = true; }
+    } restore{ctx};
     return femfct_run_graph(ctx, key, [&]() {
         for (int r = 0; r < reps; ++r) {
+            ctx->level_bias = r * delta; ctx->ord_bias = r; ctx->rep_total = reps; ctx->rep_last = (r == reps - 1);
             int rc = enqueue_one();
             if (rc != FEMFCT_OK) return rc;
         }
         return (int)FEMFCT_OK;
     });
+}
+
+// level-indirected reference of the step being enqueued (see femfct_run_graph_reps)
+static inline VecRef lref(const femfct_ctx* ctx, const double* p, const int32_t* level, int64_t stride, int32_t off) {
+    return make_ref(p, level, stride, off + (level ? ctx->level_bias : 0));
 }
 
 // Replays `step(jacobi_budget, krylov_budget, reps)` until num_steps are done, then inspects the per-step solver

@@ -37,7 +37,7 @@ int enqueue_axpby_level(femfct_ctx* ctx, int64_t count, double alpha, const doub
     int64_t g = (count + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_axpby_level, dim3((unsigned)g), dim3(256), 0, ctx->stream, count, alpha, a, beta, b, scale,
-                       ctx->d_level, off, out);
+                       ctx->d_level, off + ctx->level_bias, out);
     return FEMFCT_OK;
 }
 
@@ -59,10 +59,11 @@ int upload_wind_scale(femfct_ctx* ctx, const double* scale_host, int32_t num_ste
     return FEMFCT_OK;
 }
 
-struct Lv {  // VecRef factory bound to the ctx level counter
+struct Lv {  // VecRef factory bound to the ctx level counter (and to the step of the graph being enqueued)
+    const femfct_ctx* ctx;
     const int32_t* lv;
     int64_t n;
-    VecRef operator()(const double* base, int off) const { return make_ref(base, lv, n, off); }
+    VecRef operator()(const double* base, int off) const { return lref(ctx, base, lv, n, off); }
 };
 
 #define KEY(...) femfct_ctx::GraphKey { __VA_ARGS__ }
@@ -176,7 +177,7 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
     ARG_TRY(ctx, Aw_ell && c_level && u_traj, "null argument");
     if ((rc = femfct_ensure_traj_ws(ctx, batch, num_steps)) != FEMFCT_OK) return rc;
     const int64_t n = ctx->n, wn = (int64_t)ctx->W * n, ts = (int64_t)(num_steps + 1) * n;
-    Lv L{ctx->d_level, n};
+    Lv L{ctx, ctx->d_level, n};
     auto begin = [&]() {
         // FCT_alg_ref(-Mat_var1, ...): A = eps*Ad - Aw (helpers.py:935,957); rhs = assemble(c*v*dx) (:956)
         for (int32_t b = 0; b < batch; ++b) femfct_enqueue_axpby(ctx, wn, eps, ctx->d_Ad, -1.0, Aw_ell, ctx->d_trA + b * wn);
@@ -187,7 +188,7 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
     auto step = [&](int budget, int, int reps) {
         auto key = KEY((uint64_t)10, key_bits(Aw_ell), key_bits(c_level), key_bits(u_traj), key_bits(num_steps),
                        key_bits(dt), key_bits(eps), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol));
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, +1, [&]() {
             WMassSpec ws;  // Mat_rhs = -M + M_u2/3 (helpers.py:953-955)
             ws.alpha = -1.0; ws.beta = 1.0 / 3.0; ws.f1 = L(u_traj, 0); ws.f2 = L(u_traj, 0); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trN, batch);
@@ -210,7 +211,7 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
     ARG_TRY(ctx, Aw_ell && u_traj && uhat_T && p_traj, "null argument");
     if ((rc = femfct_ensure_traj_ws(ctx, batch, num_steps)) != FEMFCT_OK) return rc;
     const int64_t n = ctx->n, wn = (int64_t)ctx->W * n, ts = (int64_t)(num_steps + 1) * n;
-    Lv L{ctx->d_level, n};
+    Lv L{ctx, ctx->d_level, n};
     auto begin = [&]() {
         for (int32_t b = 0; b < batch; ++b) femfct_enqueue_axpby(ctx, wn, eps, ctx->d_Ad, 1.0, Aw_ell, ctx->d_trA + b * wn);
         return terminal_diff(ctx, uhat_T, u_traj, p_traj, num_steps, batch);
@@ -219,7 +220,7 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
         auto key = KEY((uint64_t)11, key_bits(Aw_ell), key_bits(u_traj), key_bits(uhat_T), key_bits(p_traj),
                        key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(batch), key_bits((int32_t)budget),
                        key_bits(ctx->rel_tol));
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, -1, [&]() {
             WMassSpec ws;  // Mat_rhs = M_u2(u_n) - M (helpers.py:1032-1034)
             ws.alpha = -1.0; ws.beta = 1.0; ws.f1 = L(u_traj, 0); ws.f2 = L(u_traj, 0); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trN, batch);
@@ -256,7 +257,7 @@ int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double
     if ((rc = femfct_ensure_krylov_ws(ctx, batch)) != FEMFCT_OK) return rc;
     const double Du = par[0], Dv = par[1], c_b = par[2], gam = par[3], om1 = par[4], om2 = par[5];
     const int64_t n = ctx->n, wn = (int64_t)ctx->W * n, ts = (int64_t)(num_steps + 1) * n;
-    Lv L{ctx->d_level, n};
+    Lv L{ctx, ctx->d_level, n};
     const double* wsc = nullptr;
     if ((rc = upload_wind_scale(ctx, wind_scale_host, num_steps, &wsc)) != FEMFCT_OK) return rc;
     // the wind-dependent operators: once per sweep for a stationary wind, once per step (level + lvoff) otherwise
@@ -283,7 +284,7 @@ int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double
                        key_bits(om1), key_bits(om2), key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget),
                        key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
                        key_bits((int32_t)femfct_species_cheb(ctx, 12)), key_bits(wsc));
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, +1, [&]() {
             if (wsc) wind_ops(1);       // wind.t = t_{n+1} (helpers.py:565-566)
             LoadSpec l1;  // (gamma/r*c + gamma*u_n^2*v_n)*v*dx  (helpers.py:584-585)
             l1.s1 = 1.0; l1.k1 = gam / rescaling; l1.p1 = make_ref(c_level); l1.p1_bs = n;
@@ -333,7 +334,7 @@ int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const doubl
     if ((rc = femfct_ensure_krylov_ws(ctx, batch)) != FEMFCT_OK) return rc;
     const double Du = par[0], Dv = par[1], gam = par[3], om1 = par[4], om2 = par[5];
     const int64_t n = ctx->n, wn = (int64_t)ctx->W * n, ts = (int64_t)(num_steps + 1) * n;
-    Lv L{ctx->d_level, n};
+    Lv L{ctx, ctx->d_level, n};
     const double* wsc = nullptr;
     if ((rc = upload_wind_scale(ctx, wind_scale_host, num_steps, &wsc)) != FEMFCT_OK) return rc;
     auto wind_ops = [&](int lvoff) {
@@ -365,7 +366,7 @@ int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const doubl
                        key_bits(Du), key_bits(Dv), key_bits(gam), key_bits(om1), key_bits(om2), key_bits(batch),
                        key_bits(alltime), key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
                        key_bits((int32_t)femfct_species_cheb(ctx, 13)), key_bits(wsc));
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, -1, [&]() {
             if (wsc) wind_ops(0);       // level counter = n: wind.t = t_n (helpers.py:664,679)
             // q first (helpers.py:683-686): Mat_q = M + dt*(Dv*Ad - omega2*A' + gamma*M_u2(u_n))
             WMassSpec wq;
@@ -410,7 +411,7 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
     if ((rc = femfct_ensure_krylov_ws(ctx, batch)) != FEMFCT_OK) return rc;
     const double delta = par[0], Dm = par[1], Df = par[2], chi = par[3], eta = par[4];
     const int64_t n = ctx->n, ts = (int64_t)(num_steps + 1) * n;
-    Lv L{ctx->d_level, n};
+    Lv L{ctx, ctx->d_level, n};
     auto begin = [&]() {
         WMassSpec ws;  // Mat_var2 = M + dt*(Df*Ad + delta*M)  (helpers.py:1308), constant SPD, shared
         ws.alpha = 1.0 + dt * delta; ws.gamma = dt * Df; ws.base = ctx->d_Ad;
@@ -422,7 +423,7 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
                        key_bits(rescaling), key_bits(batch), key_bits((int32_t)budget), key_bits((int32_t)kbudget),
                        key_bits(ctx->rel_tol), key_bits(ctx->kry_tol),
                        key_bits((int32_t)femfct_species_cheb(ctx, 14)));
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, +1, [&]() {
             LoadSpec l2;  // assemble(v_n*v*dx + dt*c*u_n/r*v*dx)  (helpers.py:1339-1340)
             l2.s0 = 1.0; l2.mx = L(v_traj, 0); l2.mx_bs = ts; l2.s1 = dt / rescaling; l2.k2 = 1.0;
             l2.q1 = make_ref(c_level); l2.q1_bs = n; l2.q2 = L(u_traj, 0); l2.q2_bs = ts;
@@ -455,7 +456,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
     if ((rc = femfct_ensure_krylov_ws(ctx, batch)) != FEMFCT_OK) return rc;
     const double delta = par[0], Dm = par[1], Df = par[2], chi = par[3], eta = par[4];
     const int64_t n = ctx->n, ts = (int64_t)(num_steps + 1) * n;
-    Lv L{ctx->d_level, n};
+    Lv L{ctx, ctx->d_level, n};
     auto begin = [&]() {
         WMassSpec ws;  // Mat_q = M + dt*(Df*Ad + delta*M)  (helpers.py:1536)
         ws.alpha = 1.0 + dt * delta; ws.gamma = dt * Df; ws.base = ctx->d_Ad;
@@ -472,7 +473,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
                        key_bits(Dm), key_bits(Df), key_bits(chi), key_bits(eta), key_bits(rescaling), key_bits(alltime),
                        key_bits(batch), key_bits((int32_t)budget), key_bits((int32_t)kbudget), key_bits(ctx->rel_tol),
                        key_bits(ctx->kry_tol), key_bits((int32_t)femfct_species_cheb(ctx, 15)));
-        return femfct_run_graph_reps(ctx, key, reps, [&]() {
+        return femfct_run_graph_reps(ctx, key, reps, -1, [&]() {
             // Mat_p = Dm*Ad - chi*Aa'(u_n, v_n)  (helpers.py:1499-1503)
             femfct_enqueue_chtxs_matrix(ctx, 1, L(u_traj, 0), ts, L(v_traj, 0), ts, Dm, chi, eta, ctx->d_trA, batch);
             LoadSpec lp;  // assemble(c_n*q_{n+1}/r*w*dx) [+ uhat_n - u_n]  (helpers.py:1505-1507)
