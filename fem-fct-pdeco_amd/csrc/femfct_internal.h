@@ -233,7 +233,7 @@ int femfct_enqueue_tile_cheb(femfct_ctx* ctx, const TilePlan& pl, const double* 
                              double md_scale, double* bufA0, double* bufA1, double* bufB0, double* bufB1, int32_t batch,
                              const struct ChebIO* io = nullptr);
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
-                                   struct VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end, int half_d = 0);
+                                   struct VecRef out, int64_t out_bstride, int32_t batch, bool* fuse_end_io, int half_d = 0);
 int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, struct MatRef A, struct VecRef rhs, int64_t rhs_bstride, double* ulow,
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch, int* tail_first = nullptr);

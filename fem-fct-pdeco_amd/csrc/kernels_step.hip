@@ -740,8 +740,8 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
     if (step_done) {
         // limiter already ran inside the fused tail
     } else if (tiles) {
-        const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
-        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch, fuse_end, half_d);
+        bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
+        femfct_enqueue_tile_flux_limit(ctx, ctx->d_D, ulow, ctx->d_du, dt, u_out, out_bstride, batch, &fuse_end, half_d);
         if (fuse_end) ctx->end_fused = true;
     } else {
         LAUNCH_W(KC_FLUX, k_flux, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_M, ctx->d_D, ulow, ctx->d_du, ctx->d_ml, dt,

@@ -707,14 +707,25 @@ struct EndArgs {
 // extra barrier, nothing at the kernel's end.  The last step keeps the ticket: the workgroup that draws the last one
 // logs and moves the counters for all R steps (every workgroup has resolved its level-dependent addresses before it
 // draws a ticket, so moving the level is safe).  Measured at C2: the per-step ticket cost 6 of 37 us.
+// (the records are 64 bytes each: copied word by word, one load and one store per thread -- a struct copy per thread
+// costs the limiter, which runs at its 64-VGPR limit, spills in its load phase)
+static_assert(sizeof(StepCtl) == 64 && sizeof(KrylovCtl) == 64, "step records are copied as 16 words");
+__device__ __forceinline__ void step_log_copy(const EndArgs& e, int ord) {
+    const int nw = e.batch * 16;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(e.ctl);
+    uint32_t* d = reinterpret_cast<uint32_t*>(e.log + (int64_t)ord * e.batch);
+    for (int t = threadIdx.x; t < nw; t += blockDim.x) d[t] = s[t];
+    if (e.kctl) {
+        const uint32_t* ks = reinterpret_cast<const uint32_t*>(e.kctl);
+        uint32_t* kd = reinterpret_cast<uint32_t*>(e.klog + (int64_t)ord * e.batch);
+        for (int t = threadIdx.x; t < nw; t += blockDim.x) kd[t] = ks[t];
+    }
+}
+
 __device__ __forceinline__ void step_log_early(const EndArgs& e) {
     if (!e.level || e.ord_adv != 0) return;
     if (blockIdx.x | blockIdx.y | blockIdx.z) return;
-    const int ord = e.level[1] + e.ord_off;
-    for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
-        e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
-        if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
-    }
+    step_log_copy(e, e.level[1] + e.ord_off);
 }
 
 __device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
@@ -728,11 +739,7 @@ __device__ __forceinline__ void step_end_by_last_workgroup(const EndArgs& e) {
     __syncthreads();
     if (is_last) {
         const int ord0 = e.level[1];
-        const int ord = ord0 + e.ord_off;
-        for (int b = threadIdx.x; b < e.batch; b += blockDim.x) {
-            e.log[(int64_t)ord * e.batch + b] = e.ctl[b];
-            if (e.kctl) e.klog[(int64_t)ord * e.batch + b] = e.kctl[b];
-        }
+        step_log_copy(e, ord0 + e.ord_off);
         __syncthreads();
         if (threadIdx.x == 0) {
             e.level[0] += e.delta;
@@ -753,6 +760,17 @@ __device__ __forceinline__ int mass_edge_counts(int gx, int gy, int nc) {
 
 #define FL_H 2
 // (two 1024-thread workgroups per CU need <= 64 VGPRs: the second launch-bound argument is waves per SIMD)
+// LDS slot of neighbour s of this thread's node (clamped into the patch, as TileGeom::nb), recomputed from the thread
+// index at every use: kept in registers across the limiter's three phases the six slots are what the 32-patch variant
+// (64-VGPR limit) spills -- 12 bytes per lane, 66 MB of scratch traffic per launch at 2049^2
+template <int PL>
+__device__ __forceinline__ int fl_nb(int s) {
+    const int lx = threadIdx.x % PL, ly = threadIdx.x / PL;
+    const int dx = (s == 0 || s == 1) ? 1 : (s == 3 || s == 4) ? -1 : 0;
+    const int dy = (s == 1 || s == 2) ? 1 : (s == 4 || s == 5) ? -1 : 0;
+    return min(max(ly + dy, 0), PL - 1) * (PL + 1) + min(max(lx + dx, 0), PL - 1);
+}
+
 template <int FL_L, int GEOM, int HALFD>   // patch edge: 16 (256 threads, many workgroups: small meshes) or 32 (less halo re-reading)
 __global__ void __launch_bounds__(FL_L * FL_L, FL_L == 32 ? 8 : 1)
 k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const double* __restrict__ D_,
@@ -762,6 +780,10 @@ k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const do
     constexpr int FL_LD = FL_L + 1, FL_T = FL_L - 2 * FL_H;
     __shared__ double su[FL_L * FL_LD], sd[FL_L * FL_LD], srp[FL_L * FL_LD], srm[FL_L * FL_LD];
     __shared__ double sdf[HALFD ? 3 : 1][HALFD ? FL_L * FL_LD : 1];   // HALFD: the forward slots (E, NE, N) of D
+    // The step end is folded in for the 16-patch only (meshes up to 512^2, where a launch counts); the 32-patch runs at
+    // its 64-VGPR limit (two 1024-thread workgroups per CU) and every spilled dword there is 44 MB of scratch traffic
+    // at 2049^2 -- its step end stays a separate tiny launch (femfct_enqueue_tile_flux_limit reports fuse_end back).
+    if (FL_L == 16) step_log_early(e);
     const int bz = blockIdx.z;
     const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
     const TileGeom g = tile_geom<FL_T, FL_H, FL_L>(N);
@@ -776,7 +798,6 @@ k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const do
 #pragma unroll
         for (int s = 0; s < 3; ++s) sdf[s][g.self] = dfw[s];
     }
-    step_log_early(e);        // (behind this kernel's own loads: its round trip rides on theirs)
     su[g.self] = ui;
     sd[g.self] = dui;
     srp[g.self] = 1.0;
@@ -792,18 +813,19 @@ k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const do
 #pragma unroll
         for (int s = 1; s < W; ++s) {
             const int64_t idx = (int64_t)s * n + g.i;
-            const double uj = su[g.nb[s - 1]];
+            const int nbs = fl_nb<FL_L>(s - 1);
+            const double uj = su[nbs];
             const double mij = GEOM ? (double)((pc >> (2 * (s - 1))) & 3) * mq : M[idx];
             double dij;
             if (HALFD) {
                 // backward slots W, SW, S: the neighbour's forward entry (a neighbour outside the grid has none:
                 // its clamped LDS slot aliases a patch node)
                 const bool exists = ((pc >> (2 * (s - 1))) & 3) != 0;
-                dij = s <= 3 ? dfw[s - 1] : (exists ? sdf[s - 4][g.nb[s - 1]] : 0.0);
+                dij = s <= 3 ? sdf[s - 1][g.self] : (exists ? sdf[s - 4][nbs] : 0.0);   // (own entries re-read from LDS: six registers less across the barrier)
             } else {
                 dij = D_[moff + idx];
             }
-            const double fs = mij * (dui - sd[g.nb[s - 1]]) + dij * (ui - uj);
+            const double fs = mij * (dui - sd[nbs]) + dij * (ui - uj);
             f[s - 1] = fs;
             pp += fmax(fs, 0.0);
             pm += fmin(fs, 0.0);
@@ -824,13 +846,14 @@ k_tile_flux_limit(int n, int N, double h, const double* __restrict__ M, const do
 #pragma unroll
         for (int s = 0; s < W - 1; ++s) {
             const double fs = f[s];
-            const double a = (fs > 0.0) ? fmin(rpi, srm[g.nb[s]]) : fmin(rmi, srp[g.nb[s]]);
+            const int nbs = fl_nb<FL_L>(s);
+            const double a = (fs > 0.0) ? fmin(rpi, srm[nbs]) : fmin(rmi, srp[nbs]);
             fbar += a * fs;
         }
         double* out = const_cast<double*>(vec_ptr(out_ref)) + bz * out_bstride;
         out[g.i] = ui + dt * fbar / mli;
     }
-    step_end_by_last_workgroup(e);
+    if (FL_L == 16) step_end_by_last_workgroup(e);
 }
 
 }  // namespace
@@ -876,13 +899,13 @@ k_tile_cheb_flux_limit(int n, int N, double h, const double* __restrict__ M, con
         ui = ulow_[voff + g.i];
         mli = ml[g.i];
     }
-    step_log_early(e);        // (behind this kernel's own loads: its round trip rides on theirs)
     ys[0][g.self] = yo;
     ys[1][g.self] = ym;
     su[g.self] = ui;
     srp[g.self] = 1.0;
     srm[g.self] = 1.0;
     __syncthreads();
+    step_log_early(e);        // (behind this kernel's own loads; its round trip is covered by the Chebyshev iterations)
     int io = 0, im = 1, in_ = 2;
     for (int k = 0; k < K; ++k) {
         const double* ymd = ys[im];
@@ -981,8 +1004,11 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
     return FEMFCT_OK;
 }
 
+// *fuse_end (in/out): whether this launch also does the step end (only the 16-patch variant can: see the kernel)
 int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const double* ulow, const double* du, double dt,
-                                   VecRef out, int64_t out_bstride, int32_t batch, bool fuse_end, int half_d) {
+                                   VecRef out, int64_t out_bstride, int32_t batch, bool* fuse_end_io, int half_d) {
+    const bool fuse_end = fuse_end_io && *fuse_end_io && ctx->N <= 512;
+    if (fuse_end_io) *fuse_end_io = fuse_end;
     EndArgs e;
     e.level = nullptr;
     if (fuse_end) {
