@@ -681,10 +681,10 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
         part_count = femfct_tile_big(ctx, tp) ? -1 : tp.tiles * tp.tiles;
         ipu = tp.K;
         exact_k = (femfct_tile_big(ctx, tp) || !ctx->exact_iters) ? 0 : tp.K;
-        // two launches, the first of which builds the operator, and the fused du/dt kernel behind them: the residual
-        // test moves out of launch 1 into that kernel (exact_k = -1; solve_ctl.h: deferred_test_*)
-        const bool defer = ctx->defer_check && fused_build && units == 2 && exact_k == 0 && ctx->fuse_dudt;
-        if (defer) exact_k = -1;
+        // two to four launches, the first of which builds the operator, and the fused du/dt kernel behind them: the
+        // residual tests move out of the later launches into that kernel (exact_k = -1; solve_ctl.h: deferred_test_*)
+        const bool defer = ctx->defer_check && fused_build && units >= 2 && units <= 4 && exact_k == 0 && ctx->fuse_dudt;
+        if (defer) exact_k = -units;
         if (fused_build)
             femfct_enqueue_tile_build_jacobi(ctx, tp, A, N, nshared, rhs, rhs_bstride, u_n, u_bstride, dt, batch);
         for (int s = fused_build ? 1 : 0; s < units; ++s)

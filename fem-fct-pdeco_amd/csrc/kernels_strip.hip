@@ -371,7 +371,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     // residual the previous launch left.  In the fused case all three come out of one reduction pass.
     double rmax_prev = 0.0;
     bool have_rmax = false;
-    // defer: second and last launch of a solve whose first launch built the operator -- nothing is reduced and nothing
+    // defer: a later launch of a solve of <= 4 launches whose first launch built the operator -- nothing is reduced and nothing
     // tested here (the test of launch 0's residual practically never passes; waiting for its partials costs this launch
     // ~2 us of its ~10); workgroup 0 of k_tile_dudt_cheb reduces everything at once (solve_ctl.h, deferred_test_*)
     if (defer) {
@@ -488,6 +488,7 @@ k_tile_jacobi(int n, int N, const double* __restrict__ L_, const double* __restr
     rmax = block_reduce(rmax, OpMax(), 0.0, smem);
     if (threadIdx.x == 0) {
         if (BIG) bigpart[(int64_t)bz * nwg + wg] = rmax;
+        else if (defer) partk[((int64_t)bz * 16 + launch) * FEMFCT_MAX_PARTIALS + wg] = rmax;   // one slot per launch
         else p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
     }
 }
@@ -1097,14 +1098,14 @@ int femfct_enqueue_tile_jacobi(femfct_ctx* ctx, const TilePlan& pl, const double
                                double* xb, int launch, int g_build, int32_t batch, bool last, int bn_launch, int defer) {
     const bool big = femfct_tile_big(ctx, pl);
     double* bigp = big ? ctx->d_bigpart : nullptr;
-    double* pk = (last && !big) ? ctx->d_partk : nullptr;
+    double* pk = ((last || defer) && !big) ? ctx->d_partk : nullptr;
     dim3 grid(pl.tiles, pl.tiles, batch);
     femfct_prof_begin(ctx, KC_JACOBI);
 #define TJ(HH)                                                                                                          \
     do {                                                                                                                \
         if (big) hipLaunchKernelGGL((k_tile_jacobi<8, 0, 1>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b,  \
                                     xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch, 0); \
-        else if (pk) hipLaunchKernelGGL((k_tile_jacobi<HH, 1, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, \
+        else if (pk && !defer) hipLaunchKernelGGL((k_tile_jacobi<HH, 1, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, \
                                         b, xa, xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch, 0); \
         else hipLaunchKernelGGL((k_tile_jacobi<HH, 0, 0>), grid, dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa, \
                                 xb, ctx->d_part, ctx->d_ctl, launch, pl.K, g_build, ctx->rel_tol, bigp, pk, bn_launch, defer); \
@@ -1184,12 +1185,12 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
     // depends on the test's outcome, only the step log does -- workgroup 0 alone reduces the partials, requested here
     // and consumed after its own tile, so that nobody waits for them (nor for a look at the control block)
     const int parity = exact_k < 0 ? (budget & 1) : ctl->done ? ctl->parity : (budget & 1);
-    DeferredPartials dp{0.0, 0.0, 0.0, INFINITY};
+    DeferredPartials dp{};
     if (exact_k >= 0)
         finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
                        partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
     else if (wg == 0)
-        dp = deferred_test_load(p, part_count);
+        dp = deferred_test_load(p, partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS, part_count, -exact_k);
     const int64_t voff = (int64_t)bz * n;
     const double* A = mat_ptr(A_ref, bz);
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -1249,7 +1250,7 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         omid_[voff + g.i] = ys[im][g.self];
         if (oold_) oold_[voff + g.i] = ys[io][g.self];
     }
-    if (exact_k < 0 && wg == 0) deferred_test_publish(ctl, dp, iters_per_unit, rel_tol);
+    if (exact_k < 0 && wg == 0) deferred_test_publish(ctl, dp, -exact_k, iters_per_unit, rel_tol);
 }
 
 }  // namespace

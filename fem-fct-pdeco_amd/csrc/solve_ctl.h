@@ -4,21 +4,29 @@
 #include "femfct_internal.h"
 #include "device_utils.h"
 
-// Deferred test of a two-launch solve (launch 0 = k_tile_build_jacobi, launch 1 = k_tile_jacobi with defer = 1): neither
-// Jacobi launch looked at a partial, so ||b||, the minimal row sum and the two residual maxima are all reduced by the
-// kernel behind them, in one pass, and the verdict a launch-1 test would have
-// reached is reconstructed.  Split in two so that the caller (workgroup 0 of k_tile_dudt_cheb) can request the partials
-// before its tile work and publish after it.  What differs from the in-launch test: had launch 0 already converged,
-// launch 1 ran nevertheless (its sweeps only lower the residual further; the iterate returned is the budget-parity one).
-struct DeferredPartials { double r0, r1, bn, rs; };
+// Deferred test of a solve of U <= 4 launches (launch 0 = k_tile_build_jacobi, launches 1.. = k_tile_jacobi with
+// defer = 1): no Jacobi launch looked at a partial, so ||b||, the minimal row sum and the U residual maxima are all
+// reduced by the kernel behind them, in one pass, and the verdict the in-launch tests would have reached is
+// reconstructed (the first launch whose residual passed gives the sweep count the host budgets from).  Split in two so
+// that the caller (wave 0 of workgroup 0 of k_tile_dudt_cheb) can request the partials before its tile work and
+// publish after it: no LDS, no barrier -- the publish is a handful of lane shifts at the kernel's end.  What differs
+// from the in-launch test: had an earlier launch already converged, the later ones ran nevertheless (their sweeps only
+// lower the residual further; the iterate returned is the budget-parity one).
+// Residual maxima: launch 0 at p[0 .. G), launch s >= 1 at partk[s * FEMFCT_MAX_PARTIALS ..).
+constexpr int FEMFCT_DEFER_MAX_UNITS = 4;
+struct DeferredPartials { double r[FEMFCT_DEFER_MAX_UNITS], bn, rs; };
 
-// (wave 0 of the calling workgroup only: no LDS, no barrier -- the publish is a handful of lane shifts at the kernel's end)
-__device__ __forceinline__ DeferredPartials deferred_test_load(const double* p, int G) {
-    DeferredPartials d{0.0, 0.0, 0.0, INFINITY};
+__device__ __forceinline__ DeferredPartials deferred_test_load(const double* p, const double* partk, int G, int units) {
+    DeferredPartials d;
+#pragma unroll
+    for (int s = 0; s < FEMFCT_DEFER_MAX_UNITS; ++s) d.r[s] = 0.0;
+    d.bn = 0.0; d.rs = INFINITY;
     if (threadIdx.x < WAVE) {
         for (int k = threadIdx.x; k < G; k += WAVE) {
-            d.r0 = fmax(d.r0, p[k]);
-            d.r1 = fmax(d.r1, p[FEMFCT_MAX_PARTIALS + k]);
+            d.r[0] = fmax(d.r[0], p[k]);
+#pragma unroll
+            for (int s = 1; s < FEMFCT_DEFER_MAX_UNITS; ++s)
+                if (s < units) d.r[s] = fmax(d.r[s], partk[(int64_t)s * FEMFCT_MAX_PARTIALS + k]);
             d.bn = fmax(d.bn, p[2 * FEMFCT_MAX_PARTIALS + k]);
             d.rs = fmin(d.rs, p[3 * FEMFCT_MAX_PARTIALS + k]);
         }
@@ -26,19 +34,30 @@ __device__ __forceinline__ DeferredPartials deferred_test_load(const double* p, 
     return d;
 }
 
-__device__ __forceinline__ void deferred_test_publish(StepCtl* ctl, DeferredPartials d, int iters_per_unit, double rel_tol) {
+__device__ __forceinline__ void deferred_test_publish(StepCtl* ctl, DeferredPartials d, int units, int iters_per_unit,
+                                                      double rel_tol) {
     if (threadIdx.x >= WAVE) return;
-    const double r0 = wave_reduce(d.r0, OpMax()), r1 = wave_reduce(d.r1, OpMax());
+    double r[FEMFCT_DEFER_MAX_UNITS];
+#pragma unroll
+    for (int s = 0; s < FEMFCT_DEFER_MAX_UNITS; ++s) r[s] = wave_reduce(d.r[s], OpMax());
     const double bn = wave_reduce(d.bn, OpMax()), rs = wave_reduce(d.rs, OpMin());
     if (threadIdx.x == 0) {
         ctl->bnorm = bn;
         ctl->min_rowsum = rs;
         if (!(rs > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
         const double tolb = rel_tol * bn;
-        if (r0 <= tolb) { ctl->iters = iters_per_unit; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS; }
-        else ctl->iters = 2 * iters_per_unit;
-        ctl->resid = bn > 0.0 ? r1 / bn : 0.0;
-        if (!(r1 <= tolb) && !(r0 <= tolb)) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
+        int first = -1;
+        double rlast = 0.0;
+#pragma unroll
+        for (int s = 0; s < FEMFCT_DEFER_MAX_UNITS; ++s)
+            if (s < units) {
+                if (first < 0 && r[s] <= tolb) first = s;
+                rlast = r[s];
+            }
+        ctl->iters = (first >= 0 ? first + 1 : units) * iters_per_unit;
+        if (first >= 0 && first < units - 1) ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
+        if (first < 0) ctl->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
+        ctl->resid = bn > 0.0 ? rlast / bn : 0.0;
     }
 }
 
