@@ -138,27 +138,59 @@ __device__ __forceinline__ void build_low_body(int n, int Wrt, int Nw, const int
         op.row(i, mask);
         double dsum = 0.0, rs = 0.0;
         unsigned nzrow = 0;
+        if constexpr (WT != 0) {
+            // Every load of the row first, the stores last: the operator's arrays are not known to be distinct from L / D
+            // (plain pointers inside the functor), so a store inside the slot loop pins the next slot's loads behind it --
+            // six dependent round trips per row instead of one (k_build_low_sb at 2049^2: 167 us, latency- not
+            // bandwidth-bound).
+            double lrow[WT - 1], drow[WT - 1];
 #pragma unroll
-        for (int s = 1; s < W; ++s) {
-            int64_t idx = (int64_t)s * n + i;
-            int j = col_of<IMP>(cols, n, Nw, mask, s, i);
-            int ts = tslot_of<IMP>(tslot, n, mask, s, i);
-            double a = op.a(s, i);
-            double at = op.at(s, i, j, ts);
-            double d = (j != i) ? fmax(0.0, fmax(a, at)) : 0.0;   // d_ij = max(0, a_ij, a_ji)
-            dsum += d;
-            double l = dt * (a - d);
-            if (Nm) l += dt * Nm[idx];
-            if (!half_d || s <= 3) D[idx] = d;
-            rs += l;
-            // which entries of this row are exactly zero (the low-order operator is an upwind stencil: about half of its
-            // off-diagonals vanish): six bits per row, one byte per node.  With the mask in force its only reader
-            // (k_strip4_jacobi[_walk]) never touches a vanishing entry, so those are not stored either: a 128-byte
-            // line of zeros is neither written here nor read there.
-            if (lmask) {
-                if (l != 0.0) { L[idx] = l; nzrow |= 1u << (s - 1); }
-            } else {
-                L[idx] = l;
+            for (int s = 1; s < WT; ++s) {
+                const int64_t idx = (int64_t)s * n + i;
+                const int j = col_of<IMP>(cols, n, Nw, mask, s, i);
+                const int ts = tslot_of<IMP>(tslot, n, mask, s, i);
+                const double a = op.a(s, i);
+                const double at = op.at(s, i, j, ts);
+                const double d = (j != i) ? fmax(0.0, fmax(a, at)) : 0.0;   // d_ij = max(0, a_ij, a_ji)
+                dsum += d;
+                double l = dt * (a - d);
+                if (Nm) l += dt * Nm[idx];
+                rs += l;
+                lrow[s - 1] = l;
+                drow[s - 1] = d;
+            }
+#pragma unroll
+            for (int s = 1; s < WT; ++s) {
+                const int64_t idx = (int64_t)s * n + i;
+                if (!half_d || s <= 3) D[idx] = drow[s - 1];
+                // which entries of this row are exactly zero (the low-order operator is an upwind stencil: about half of
+                // its off-diagonals vanish): six bits per row, one byte per node.  With the mask in force its only reader
+                // (k_strip4_jacobi[_walk]) never touches a vanishing entry, so those are not stored either: a 128-byte
+                // line of zeros is neither written here nor read there.
+                if (lmask) {
+                    if (lrow[s - 1] != 0.0) { L[idx] = lrow[s - 1]; nzrow |= 1u << (s - 1); }
+                } else {
+                    L[idx] = lrow[s - 1];
+                }
+            }
+        } else {
+            for (int s = 1; s < W; ++s) {
+                int64_t idx = (int64_t)s * n + i;
+                int j = col_of<IMP>(cols, n, Nw, mask, s, i);
+                int ts = tslot_of<IMP>(tslot, n, mask, s, i);
+                double a = op.a(s, i);
+                double at = op.at(s, i, j, ts);
+                double d = (j != i) ? fmax(0.0, fmax(a, at)) : 0.0;
+                dsum += d;
+                double l = dt * (a - d);
+                if (Nm) l += dt * Nm[idx];
+                if (!half_d || s <= 3) D[idx] = d;
+                rs += l;
+                if (lmask) {
+                    if (l != 0.0) { L[idx] = l; nzrow |= 1u << (s - 1); }
+                } else {
+                    L[idx] = l;
+                }
             }
         }
         double mli = ml[i];
