@@ -105,6 +105,31 @@ __device__ __forceinline__ double wave_reduce(double v, Op op) {
     return v;
 }
 
+// max / min over the wave with DPP lane moves instead of ds_bpermute shuffles: the shuffle version is six dependent LDS
+// round trips (~700 cycles per reduction -- a microsecond for the three reductions that end k_tile_build_jacobi); this
+// one is six register moves + ops (~100 cycles).  Order of combination does not matter for max / min (exact), so the
+// result is the same bits; sums keep the shuffle tree (their rounding depends on the order).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {      // lanes outside ROW_MASK (or without a source) keep their own v
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <class Op>
+__device__ __forceinline__ double wave_reduce_dpp(double v, Op op) {
+    v = op(v, dpp_take<0xB1, 0xf>(v));     // quad_perm [1,0,3,2]
+    v = op(v, dpp_take<0x4E, 0xf>(v));     // quad_perm [2,3,0,1]
+    v = op(v, dpp_take<0x141, 0xf>(v));    // row_half_mirror
+    v = op(v, dpp_take<0x140, 0xf>(v));    // row_mirror: every lane of a 16-lane row holds the row's result
+    v = op(v, dpp_take<0x142, 0xa>(v));    // row_bcast:15 into rows 1, 3
+    v = op(v, dpp_take<0x143, 0xc>(v));    // row_bcast:31 into rows 2, 3: lane 63 holds the wave's result
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_reduce(double v, OpMax op) { return wave_reduce_dpp(v, op); }
+__device__ __forceinline__ double wave_reduce(double v, OpMin op) { return wave_reduce_dpp(v, op); }
+
 template <class Op>
 __device__ __forceinline__ double block_reduce(double v, Op op, double identity, double* smem) {
     v = wave_reduce(v, op);
