@@ -130,6 +130,25 @@ __device__ __forceinline__ double wave_reduce_dpp(double v, Op op) {
 __device__ __forceinline__ double wave_reduce(double v, OpMax op) { return wave_reduce_dpp(v, op); }
 __device__ __forceinline__ double wave_reduce(double v, OpMin op) { return wave_reduce_dpp(v, op); }
 
+// the same tree for sums (lanes without a source add 0): a fixed order, so still deterministic
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take0(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_reduce(double v, OpSum) {
+    v += dpp_take0<0xB1, 0xf>(v);
+    v += dpp_take0<0x4E, 0xf>(v);
+    v += dpp_take0<0x141, 0xf>(v);
+    v += dpp_take0<0x140, 0xf>(v);
+    v += dpp_take0<0x142, 0xa>(v);
+    v += dpp_take0<0x143, 0xc>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 template <class Op>
 __device__ __forceinline__ double block_reduce(double v, Op op, double identity, double* smem) {
     v = wave_reduce(v, op);
