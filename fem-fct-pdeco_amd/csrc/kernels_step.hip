@@ -338,13 +338,16 @@ __device__ __forceinline__ void dudt_rhs_body(int n, int Wrt, int Nw, const int3
         const unsigned mask = nb_mask<IMP>(i, Nw);
         op.row(i, mask);
         double xi = x[i];
+        // (requested before the stores below: the compiler cannot tell M / rhs from the output arrays, and a load
+        // behind a store waits for it)
+        const double mdi = M[i], rhi = rhs ? rhs[i] : 0.0;
         double acc = op.a(0, i) * xi;
 #pragma unroll
         for (int s = 1; s < W; ++s) acc = fma(op.a(s, i), x[col_of<IMP>(cols, n, Nw, mask, s, i)], acc);
-        double r = -acc + (rhs ? rhs[i] : 0.0);
+        double r = -acc + rhi;
         rdu[i] = r;
         ulow[i] = xi;               // stable home of u_L for the flux/limit kernels
-        y1[i] = omega1 * (r / (md_scale * M[i]));
+        y1[i] = omega1 * (r / (md_scale * mdi));
     }
 }
 

@@ -1189,8 +1189,6 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
     if (exact_k >= 0)
         finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
                        partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
-    else if (wg == 0)
-        dp = deferred_test_load(p, partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS, part_count, -exact_k);
     const int64_t voff = (int64_t)bz * n;
     const double* A = mat_ptr(A_ref, bz);
     const double* x = (parity ? xb_ : xa_) + voff;
@@ -1212,6 +1210,9 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         ui = x[g.i];
         ri = rhs ? rhs[g.i] : 0.0;
     }
+    // (behind the tile's own loads, so that workgroup 0 does not start them late)
+    if (exact_k < 0 && wg == 0)
+        dp = deferred_test_load(p, partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS, part_count, -exact_k);
     ys[2][g.self] = ui;
     __syncthreads();
     // r = rhs - A u_L on every node whose neighbours are in the patch

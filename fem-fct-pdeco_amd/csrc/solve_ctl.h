@@ -22,6 +22,7 @@ __device__ __forceinline__ DeferredPartials deferred_test_load(const double* p, 
     for (int s = 0; s < FEMFCT_DEFER_MAX_UNITS; ++s) d.r[s] = 0.0;
     d.bn = 0.0; d.rs = INFINITY;
     if (threadIdx.x < WAVE) {
+#pragma unroll 4                           // (up to 256 workgroups: all loads of the wave in flight together)
         for (int k = threadIdx.x; k < G; k += WAVE) {
             d.r[0] = fmax(d.r[0], p[k]);
 #pragma unroll
