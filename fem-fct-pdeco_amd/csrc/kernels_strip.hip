@@ -2043,6 +2043,9 @@ k_strip4_cheb_mass_walk(int n, int N, double h, const double* __restrict__ b_, c
     // patches wg, wg + nwg, ...: patches on the mesh boundary (general stencil weights: slower sweeps) spread evenly
     const int q0 = wg, q1 = npatch;
     const int lx0 = threadIdx.x & 63;
+    // The two quotients of an interior node (six triangles: all but the mesh-boundary rows), once per kernel: eight f64
+    // divisions per thread and patch are ~2 us of a 13 us patch.  Same expressions, same operands: same bits.
+    const double cw6 = 1.0 / (2.0 * md_scale * 6), bs6 = 12.0 / (md_scale * 6 * h * h);
     double pb[4], pym[4], pyo[4];          // raw inputs of the patch about to be processed
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pb[r] = 0.0; pym[r] = 0.0; pyo[r] = 0.0; }
@@ -2068,13 +2071,18 @@ k_strip4_cheb_mass_walk(int n, int N, double h, const double* __restrict__ b_, c
             g[r] = strip4_node(N, r, H, (unsigned)px | ((unsigned)py << 16), lx, st);
             bv[r] = 0.0; cw[r] = 0.0; ym[r] = 0.0; yo[r] = 0.0; pc[r] = 0;
             if (g[r].inside) {
-                const int gy = g[r].i / N, gx = g[r].i - gy * N;
+                const int gx = px * (T4_L - 2 * H) - H + lx, gy = py * (T4_L - 2 * H) - H + 4 * st + r;   // (no i / N)
                 const int c00 = (gx < nc && gy < nc), c10 = (gx > 0 && gy < nc), c01 = (gx < nc && gy > 0), c11 = (gx > 0 && gy > 0);
                 const int ntri = 2 * c00 + c10 + c01 + 2 * c11;
                 pc[r] = (c00 + c01) | ((2 * c00) << 2) | ((c00 + c10) << 4) | ((c10 + c11) << 6) | ((2 * c11) << 8) | ((c11 + c01) << 10);
-                cw[r] = 1.0 / (2.0 * md_scale * ntri);
+                if (ntri == 6) {
+                    cw[r] = cw6;
+                    bv[r] = pb[r] * bs6;
+                } else {
+                    cw[r] = 1.0 / (2.0 * md_scale * ntri);
+                    bv[r] = pb[r] * (12.0 / (md_scale * ntri * h * h));
+                }
                 if (pc[r] == 0xAAA) cw[r] = 2.0 * cw[r];
-                bv[r] = pb[r] * (12.0 / (md_scale * ntri * h * h));
                 ym[r] = pym[r];
                 yo[r] = pyo[r];
             }
