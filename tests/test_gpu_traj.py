@@ -383,3 +383,45 @@ def test_graph_relative_levels_match_eager_stepping(hp, solvers):
     for a, b in ((lf_g, lf_e), (la_g, la_e)):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_walking_launches_with_a_batch(hp, solvers, monkeypatch):
+    """The persistent-workgroup launches of the bandwidth regime split their walkers over the batch members (blockIdx.z);
+    each member has its own partials, masks and carry.  Two trajectories in one batch at 331^2 with six walkers forced
+    (three per member): identical bits to the same batch with one workgroup per patch, and equal to the trajectories
+    solved one at a time up to the solver tolerance (a batch shares its sweep budget, a single solve has its own)."""
+    nc, Nt = 330, 2
+    mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
+    n = mesh.nodes
+    dt = 1e-3 * (2.0 / nc) / 0.025
+    x, y = mesh.coordinates()
+    rng = np.random.default_rng(37)
+    tl = (Nt + 1) * n
+    u0 = [np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n),
+          np.exp(-15 * ((x - 0.2) ** 2 + (y + 0.1) ** 2)) + 0.02 * rng.random(n)]
+    cs = [np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1), np.tile(0.7 + 0.3 * np.cos(2 * x + y), Nt + 1)]
+    init = np.zeros((2, tl))
+    init[0, :n], init[1, :n] = u0
+    outs = []
+    for walk in ("1", "0"):
+        monkeypatch.setenv("FEMFCT_T4_WALK", walk)
+        monkeypatch.setenv("FEMFCT_T4_WALKERS", "6")
+        prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=2, order=hp.ORDER_VERTEX)
+        try:
+            if walk == "1":
+                assert prob.ctx.patch_walkers(2) == 3 and prob.ctx.patch_walkers(1) == 6
+            else:
+                assert prob.ctx.patch_walkers(2) == 0
+            d_c, d_u = prob.ctx.array(np.concatenate(cs)), prob.ctx.array(init.reshape(-1))
+            prob.forward(d_c, d_u, batch=2)
+            assert not np.any(prob.solver_log(2)["flags"] & hp.FLAG_SOLVER_BUDGET)
+            outs.append(d_u.download().reshape(2, tl))
+            if walk == "1":
+                for b in range(2):
+                    uk = np.zeros(tl)
+                    uk[:n] = u0[b]
+                    prob.solve_state(cs[b], uk)
+                    assert rel(uk, outs[0][b]) < 1e-11, b
+        finally:
+            prob.close()
+    assert np.array_equal(outs[0], outs[1])
