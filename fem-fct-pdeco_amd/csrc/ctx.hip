@@ -255,6 +255,7 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_T4_WALK")) ctx->t4_walk = atoi(e);   // 2: walk without the carry (measurement)
     if (const char* e = getenv("FEMFCT_T4_SNAKE")) ctx->t4_snake = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_DEFER_CHECK")) ctx->defer_check = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_T4_INT")) ctx->t4_int = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_WALKERS")) { int v = atoi(e); if (v > 0) ctx->num_cus = v; }   // tests: walks on small meshes
     if (const char* e = getenv("FEMFCT_INLINE_OPS")) ctx->inline_ops = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_HALF_D")) ctx->half_d = atoi(e) != 0;

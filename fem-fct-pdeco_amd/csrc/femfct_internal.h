@@ -79,6 +79,7 @@ struct femfct_ctx {
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int t4_snake = 1;           // walking Jacobi launches alternate their direction (FEMFCT_T4_SNAKE)
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
+    int t4_int = 1;             // Chebyshev on the mesh's mass matrix: interior patches by the two-workgroups-per-CU kernel (FEMFCT_T4_INT)
     int t4_walk = 1;            // 64-patch Jacobi: persistent workgroups walk down columns of patches, shared rows carried in LDS (FEMFCT_T4_WALK)
     int num_cus = 256;          // compute units of the device (one 1024-thread walker each)
     int t4_xcd = 0;             // 64-patch kernels: x-neighbouring patches under the same XCD's L2 (FEMFCT_T4_XCD)

@@ -1956,8 +1956,19 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const double* __restrict__ ymid_,
                    const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
-                   CheOmegas om, double md_scale, int H, int remap) {
+                   CheOmegas om, double md_scale, int H, int remap, int ring) {
     __shared__ double top[2][16][64], bot[2][16][64];
+    // ring > 0: only the patches outside the interior block [1, ring]^2 (k_strip4_cheb_mass_int's) are launched, as a
+    // 1-D grid: the row below the block, the rows above it, then the columns left and right of it
+    unsigned pxy = strip4_patch(remap);
+    if (ring > 0) {
+        const int t = (N + (T4_L - 2 * H) - 1) / (T4_L - 2 * H), side = t - ring;   // patches per row, per row beside the block
+        int id = blockIdx.x, bx, by;
+        if (id < t) { bx = id; by = 0; }
+        else if (id < t * side) { id -= t; by = ring + 1 + id / t; bx = id % t; }
+        else { id -= t * side; by = 1 + id / side; const int c = id % side; bx = c == 0 ? 0 : ring + c; }
+        pxy = (unsigned)bx | ((unsigned)by << 16);
+    }
     const int64_t voff = (int64_t)blockIdx.z * n;
     const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
     const int nc = N - 1;
@@ -1967,7 +1978,6 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
     int pc[4];            // six 2-bit edge counts, slots E, NE, N, W, SW, S
     // (interior nodes -- six triangles -- share their two quotients: two f64 divisions per thread instead of eight)
     const double cw6 = 1.0 / (2.0 * md_scale * 6), bs6 = 12.0 / (md_scale * 6 * h * h);
-    const unsigned pxy = strip4_patch(remap);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         g[r] = strip4_node(N, r, H, pxy);
@@ -2028,6 +2038,64 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
             omid_[voff + g[r].i] = ym[r];
             if (oold_) oold_[voff + g[r].i] = yo[r];
         }
+}
+
+// The same iterations for patches that lie entirely in the mesh interior (every node has six triangles): no stencil
+// shapes, no per-row weights, no validity flags -- 60-odd VGPRs, so TWO 1024-thread workgroups fit a CU and each one's
+// barrier and LDS round trips are covered by the other's arithmetic (tools/sweep_probe.hip: 0.58 instead of 1.0 us per
+// patch and sweep).  One workgroup per patch, blockIdx + (px0, py0); the patches that touch the mesh boundary (the outer
+// ring of the patch grid) are left to k_strip4_cheb_mass with skip_interior = 1.  Same expressions as the interior branch
+// there: same bits.
+__global__ void __launch_bounds__(STRIP_T, 8)
+k_strip4_cheb_mass_int(int n, int N, double h, const double* __restrict__ b_, const double* __restrict__ ymid_,
+                       const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
+                       CheOmegas om, double md_scale, int H, int px0, int py0) {
+    __shared__ double top[2][16][64], bot[2][16][64];
+    const int lx = threadIdx.x & 63, st = threadIdx.x >> 6;
+    const int T = T4_L - 2 * H;
+    const double inv_scale = 1.0 / md_scale;
+    // (interior rows weight every neighbour by two: the factor sits in cw, as in k_strip4_cheb_mass)
+    const double cw = 2.0 * (1.0 / (2.0 * md_scale * 6)), bs6 = 12.0 / (md_scale * 6 * h * h);
+    const int gx = ((int)blockIdx.x + px0) * T - H + lx, gy0 = ((int)blockIdx.y + py0) * T - H + 4 * st;
+    const int64_t i0 = (int64_t)blockIdx.z * n + (int64_t)gy0 * N + gx;          // node of row 0; rows are N apart
+    double bv[4], ym[4], yo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bv[r] = b_[i0 + (int64_t)r * N] * bs6;
+        ym[r] = ymid_ ? ymid_[i0 + (int64_t)r * N] : 0.0;
+        yo[r] = yold_ ? yold_[i0 + (int64_t)r * N] : 0.0;
+    }
+    for (int k = 0; k < K; ++k) {
+        const int par = k & 1;
+        bot[par][st][lx] = ym[0];
+        top[par][st][lx] = ym[3];
+        __syncthreads();
+        const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+        const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+        STRIP4_NEIGHBOURS(ym, above, below);
+        const double wk = om.w[k];
+        double yn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double sum = ((STRIP4_NB(ym, above, below, r, 0) + STRIP4_NB(ym, above, below, r, 1)) +
+                                (STRIP4_NB(ym, above, below, r, 2) + STRIP4_NB(ym, above, below, r, 3))) +
+                               (STRIP4_NB(ym, above, below, r, 4) + STRIP4_NB(ym, above, below, r, 5));
+            const double z = fma(-cw, sum, fma(-inv_scale, ym[r], bv[r]));
+            yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
+    }
+    if (lx >= H && lx < H + T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ly = 4 * st + r;
+            if (ly >= H && ly < H + T) {
+                omid_[i0 + (int64_t)r * N] = ym[r];
+                if (oold_) oold_[i0 + (int64_t)r * N] = yo[r];
+            }
+        }
+    }
 }
 
 // k_strip4_cheb_mass with persistent workgroups (see k_strip4_jacobi_walk), each taking every gridDim.x-th patch.
@@ -2255,6 +2323,8 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
     const int per_launch = single ? ((io_in && io_in->om_dev) ? k_last - k_first + 1 : 24) : H;   // by-value omega table: 24
     const int t = femfct_tile4_tiles(ctx, H);
     const int walkers = single ? 0 : femfct_tile4_walkers(ctx, H, batch);
+    // patches 1 .. n_int (per direction) lie wholly in the mesh interior: (p + 1) T + H <= N - 1
+    const int n_int = (single || !ctx->t4_int) ? 0 : std::max(0, (ctx->N - 1 - H) / (T4_L - 2 * H) - 1);
     const size_t lds = (size_t)3 * T4_BUF * 8;
     const double* mid = in_mid;
     const double* old = in_old;
@@ -2271,12 +2341,18 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
-        if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && walkers > 0)
+        if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && n_int > 0 && (int64_t)t * t * batch > ctx->num_cus) {
+            // more patches than compute units: the interior ones two workgroups to a CU, the boundary ring by the general kernel
+            hipLaunchKernelGGL(k_strip4_cheb_mass_int, dim3(n_int, n_int, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
+                               ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, 1, 1);
+            hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t * t - n_int * n_int, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n,
+                               ctx->N, ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, 0, n_int);
+        } else if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && walkers > 0)
             hipLaunchKernelGGL(k_strip4_cheb_mass_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
                                ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, t, t * t);
         else if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in)
             hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
-                               mid, old, omid, oold, k1 - k0, om, md_scale, H, ctx->t4_xcd);
+                               mid, old, omid, oold, k1 - k0, om, md_scale, H, ctx->t4_xcd, 0);
         else if (ctx->t4_dpp)
             hipLaunchKernelGGL(k_strip4_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,
                                old, omid, oold, k1 - k0, om, md_scale, io, H, ctx->t4_xcd);
