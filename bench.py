@@ -501,7 +501,8 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     dom = kernels[dom_name]
     walkers = ctx.patch_walkers(1, sweeps // max(1, steps)) if regime == 3 else 0
     sym = {3: {"jacobi": "k_strip4_jacobi_walk" if walkers else "k_strip4_jacobi<0>",
-               "cheb": ("k_strip4_cheb_mass_walk" if walkers else "k_strip4_cheb_mass") if geom else "k_strip4_cheb"},
+               "cheb": (("k_strip4_cheb_mass_int + k_strip4_cheb_mass on the boundary ring" if os.environ.get("FEMFCT_T4_INT", "1") != "0"
+                         else "k_strip4_cheb_mass_walk") if walkers else "k_strip4_cheb_mass") if geom else "k_strip4_cheb"},
            2: {"jacobi": "k_tile_jacobi<H,0,BIG>", "cheb": "k_tile_cheb<H>"},
            1: {"jacobi": "k_strip_jacobi<RPT>", "cheb": "k_strip_cheb<RPT>"},
            0: {"jacobi": "k_jacobi<7,256,1>", "cheb": "k_cheb<7,256,1>"}}[regime][dom_name]

@@ -1953,6 +1953,7 @@ k_strip4_cheb(int n, int N, const double* __restrict__ M, const double* __restri
 // edge), so the row scaled by 1 / (md_scale m_ii) is cnt_ij / (2 md_scale ntri) -- small-integer ratios decided by
 // which of the four cells around the node exist.  HBM traffic per node and launch drops from 9 doubles (7 matrix
 // entries, rhs, iterate) to 2-3, and the interior update is one multiply of the neighbour sum.
+template <int RING>    // 1: the boundary-ring launch next to k_strip4_cheb_mass_int (its own instantiation: 48 VGPRs of weights)
 __global__ void __launch_bounds__(STRIP_T)
 k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const double* __restrict__ ymid_,
                    const double* __restrict__ yold_, double* __restrict__ omid_, double* __restrict__ oold_, int K,
@@ -1961,7 +1962,7 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
     // ring > 0: only the patches outside the interior block [1, ring]^2 (k_strip4_cheb_mass_int's) are launched, as a
     // 1-D grid: the row below the block, the rows above it, then the columns left and right of it
     unsigned pxy = strip4_patch(remap);
-    if (ring > 0) {
+    if (RING) {
         const int t = (N + (T4_L - 2 * H) - 1) / (T4_L - 2 * H), side = t - ring;   // patches per row, per row beside the block
         int id = blockIdx.x, bx, by;
         if (id < t) { bx = id; by = 0; }
@@ -2030,7 +2031,50 @@ k_strip4_cheb_mass(int n, int N, double h, const double* __restrict__ b_, const 
         }                                                                                                       \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }                         \
     }
-    if (all_interior) { CHEB_MASS_SWEEPS(true) } else { CHEB_MASS_SWEEPS(false) }
+    if (RING) {
+        // boundary-ring launch: one workgroup per CU anyway and most patches hold some boundary nodes -- every wave runs
+        // the general stencil, with the 24 edge counts decoded ONCE (48 VGPRs this launch can afford): six FMAs per row
+        // and sweep instead of six decode-and-FMA groups.  (double)cnt is the same value either way: same bits.
+        double wq[4][6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 6; ++s) wq[r][s] = (double)((pc[r] >> (2 * s)) & 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (pc[r] == 0xAAA) {          // interior rows carry the factor two in cw (see above): unit weights
+#pragma unroll
+                for (int s = 0; s < 6; ++s) wq[r][s] = 1.0;
+            }
+        for (int k = 0; k < K; ++k) {
+            const int par = k & 1;
+            bot[par][st][lx] = ym[0];
+            top[par][st][lx] = ym[3];
+            __syncthreads();
+            const double above = (st < 15) ? bot[par][st + 1][lx] : 0.0;
+            const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+            STRIP4_NEIGHBOURS(ym, above, below);
+            const double wk = om.w[k];
+            double yn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double sum;
+                if (pc[r] == 0xAAA) {
+                    sum = ((STRIP4_NB(ym, above, below, r, 0) + STRIP4_NB(ym, above, below, r, 1)) +
+                           (STRIP4_NB(ym, above, below, r, 2) + STRIP4_NB(ym, above, below, r, 3))) +
+                          (STRIP4_NB(ym, above, below, r, 4) + STRIP4_NB(ym, above, below, r, 5));
+                } else {
+                    sum = 0.0;
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) sum = fma(wq[r][s], STRIP4_NB(ym, above, below, r, s), sum);
+                }
+                const double z = fma(-cw[r], sum, fma(-inv_scale, ym[r], bv[r]));
+                yn[r] = wk * (z + ym[r] - yo[r]) + yo[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { yo[r] = ym[r]; ym[r] = yn[r]; }
+        }
+    } else if (all_interior) { CHEB_MASS_SWEEPS(true) } else { CHEB_MASS_SWEEPS(false) }
 #undef CHEB_MASS_SWEEPS
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -2345,13 +2389,13 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
             // more patches than compute units: the interior ones two workgroups to a CU, the boundary ring by the general kernel
             hipLaunchKernelGGL(k_strip4_cheb_mass_int, dim3(n_int, n_int, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
                                ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, 1, 1);
-            hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t * t - n_int * n_int, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n,
+            hipLaunchKernelGGL(k_strip4_cheb_mass<1>, dim3(t * t - n_int * n_int, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n,
                                ctx->N, ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, 0, n_int);
         } else if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && walkers > 0)
             hipLaunchKernelGGL(k_strip4_cheb_mass_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,
                                ctx->h, b, mid, old, omid, oold, k1 - k0, om, md_scale, H, t, t * t);
         else if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in)
-            hipLaunchKernelGGL(k_strip4_cheb_mass, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
+            hipLaunchKernelGGL(k_strip4_cheb_mass<0>, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->h, b,
                                mid, old, omid, oold, k1 - k0, om, md_scale, H, ctx->t4_xcd, 0);
         else if (ctx->t4_dpp)
             hipLaunchKernelGGL(k_strip4_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, ctx->d_M, b, mid,

@@ -19,9 +19,12 @@ import sys
 
 # kernel -> class, separately for the product path at the roofline size (fused multi-sweep kernels, operator derived
 # in the kernels) and for the fusions-off pass of bench.py (one-sweep kernels); both run in the same bench.py process
-PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_strip4_jacobi_walk": "jacobi", "k_strip4_cheb_mass_walk": "cheb", "k_dudt_rhs_sb": "dudt_rhs", "k_strip4_cheb_mass": "cheb",
+PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_strip4_jacobi_walk": "jacobi", "k_strip4_cheb_mass_walk": "cheb",
+           "k_strip4_cheb_mass_int": "cheb", "k_dudt_rhs_sb": "dudt_rhs", "k_strip4_cheb_mass": "cheb",
            "k_strip4_cheb": "cheb", "k_tile_flux_limit": "flux", "k_tile_jacobi": "jacobi", "k_tile_cheb": "cheb",
            "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb"}
+# a class launch that consists of two kernels: the main one and its companion (boundary ring of the patch grid)
+COMPANION = {"k_strip4_cheb_mass_int": "k_strip4_cheb_mass"}
 ONE_SWEEP = {"k_build_low": "build_low", "k_jacobi": "jacobi", "k_dudt_rhs": "dudt_rhs", "k_cheb": "cheb", "k_flux": "flux",
              "k_limit": "limit", "k_ops_solidbody": "assemble"}
 
@@ -41,6 +44,8 @@ def load(path, counter, min_grid):
             large = "<7, 256" in r["Kernel_Name"] or int(r["Grid_Size"]) >= min_grid or m.group(0).endswith("_walk")
             if large:
                 agg[m.group(0)].append(float(r["Counter_Value"]))
+            elif m.group(0) in COMPANION.values() and int(r["Grid_Size"]) >= min_grid // 8:
+                agg[m.group(0) + "+ring"].append(float(r["Counter_Value"]))     # the boundary-ring launch of a split class
     return agg
 
 
@@ -58,8 +63,11 @@ def main():
         hbm = 2 * f + w
         rows.append(dict(kernel=k, launches=len(fa[k]), fetch_size_bytes_raw=f, write_size_bytes=w,
                          hbm_bytes_per_launch=hbm, hbm_bytes_per_row=hbm / n))
-        if k in PRODUCT:
+        if k in PRODUCT and not (PRODUCT[k] == "cheb" and k != "k_strip4_cheb_mass_int" and "k_strip4_cheb_mass_int" in fa):
             traffic[PRODUCT[k]] = hbm
+            if k in COMPANION and COMPANION[k] + "+ring" in fa:
+                kr = COMPANION[k] + "+ring"
+                traffic[PRODUCT[k]] += (2 * statistics.mean(fa[kr]) + statistics.mean(wa.get(kr, [0.0]))) * 1024
         if k in ONE_SWEEP:
             traffic1[ONE_SWEEP[k]] = hbm
     with open(prefix + "_pmc_traffic.csv", "w", newline="") as f:
