@@ -68,7 +68,7 @@ struct femfct_ctx {
     std::map<int, int> kind_fail;   // largest Jacobi budget known to be too small, per kind
     std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
-    int32_t steps_per_graph = 10;   // time steps captured per hipGraph in the trajectory drivers
+    int32_t steps_per_graph = 50;   // time steps captured per hipGraph in the trajectory drivers (only the last one moves the counters)
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
     bool mesh_solve = true;         // species solves of meshes with n <= 4096 as one workgroup per system (FEMFCT_MESH_SOLVE)

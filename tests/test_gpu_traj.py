@@ -344,11 +344,12 @@ def test_deferred_residual_test_reproduces_the_in_launch_one(hp, solvers, monkey
                 assert np.array_equal(a[k], b[k]), k
 
 
-def test_graph_relative_levels_match_eager_stepping(hp, solvers):
-    """Trajectory sweeps replay captured graphs of 10 steps in which step r carries its level offset r * delta and only the
+def test_graph_relative_levels_match_eager_stepping(hp, solvers, monkeypatch):
+    """Trajectory sweeps replay captured graphs of (here) 10 steps in which step r carries its level offset r * delta and only the
     last step moves the device counters.  With graphs off every step is its own group (offset 0, counters move each step):
     same trajectories to the bit and same per-step solver records, for a step count that is not a multiple of 10, forward
     (delta = +1) and adjoint (delta = -1, all-time right-hand side)."""
+    monkeypatch.setenv("FEMFCT_STEPS_PER_GRAPH", "10")      # two full graphs and one of three steps
     nc, Nt, dt = 40, 23, 1e-3
     mesh = hp.SquareMeshP1(-1, 1, nc)
     n = mesh.nodes
