@@ -1181,11 +1181,18 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
     StepCtl* ctl = ctl_ + bz;
     double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (exact_k < 0 && blockIdx.y == gridDim.x) {
+        // deferred test: the launch carries one extra row of workgroups; its first one does nothing but reduce the solve's
+        // partials and write the step record (no tile behind it: no workgroup of the kernel ends later for it)
+        if (blockIdx.x == 0)
+            deferred_test_publish(ctl, deferred_test_load(p, partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS, part_count, -exact_k),
+                                  -exact_k, iters_per_unit, rel_tol);
+        return;
+    }
     // deferred test (exact_k < 0): no launch of the solve set `done`, the iterate is the budget-parity one; nothing below
     // depends on the test's outcome, only the step log does -- workgroup 0 alone reduces the partials, requested here
     // and consumed after its own tile, so that nobody waits for them (nor for a look at the control block)
     const int parity = exact_k < 0 ? (budget & 1) : ctl->done ? ctl->parity : (budget & 1);
-    DeferredPartials dp{};
     if (exact_k >= 0)
         finalize_solve(ctl, p, part_count, budget, iters_per_unit, rel_tol, smem,
                        partk ? partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS : nullptr, exact_k, wg == 0);
@@ -1210,9 +1217,6 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         ui = x[g.i];
         ri = rhs ? rhs[g.i] : 0.0;
     }
-    // (behind the tile's own loads, so that workgroup 0 does not start them late)
-    if (exact_k < 0 && wg == 0)
-        dp = deferred_test_load(p, partk + (int64_t)bz * 16 * FEMFCT_MAX_PARTIALS, part_count, -exact_k);
     ys[2][g.self] = ui;
     __syncthreads();
     // r = rhs - A u_L on every node whose neighbours are in the patch
@@ -1251,7 +1255,6 @@ k_tile_dudt_cheb(int n, int N, MatRef A_ref, VecRef rhs_ref, int64_t rhs_bstride
         omid_[voff + g.i] = ys[im][g.self];
         if (oold_) oold_[voff + g.i] = ys[io][g.self];
     }
-    if (exact_k < 0 && wg == 0) deferred_test_publish(ctl, dp, -exact_k, iters_per_unit, rel_tol);
 }
 
 }  // namespace
@@ -1271,7 +1274,7 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, MatRef A, VecRef rhs, int64_t
     double* omid = last ? ctx->d_du : ctx->d_y0;
     double* oold = last ? nullptr : ctx->d_y2;
     femfct_prof_begin(ctx, KC_DUDT_RHS);
-    hipLaunchKernelGGL(k_tile_dudt_cheb, dim3(t, t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, A, rhs,
+    hipLaunchKernelGGL(k_tile_dudt_cheb, dim3(t, exact_k < 0 ? t + 1 : t, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, A, rhs,
                        rhs_bstride, ctx->d_M, ctx->d_xa, ctx->d_xb, ulow, ctx->d_rdu, omid, oold, ctx->d_part, ctx->d_ctl,
                        budget_units, part_count, iters_per_unit, ctx->rel_tol, exact_k ? ctx->d_partk : nullptr, exact_k,
                        K, om, md_scale, omegas[0]);
