@@ -318,6 +318,7 @@ def test_deferred_residual_test_reproduces_the_in_launch_one(hp, solvers, monkey
             monkeypatch.setenv("FEMFCT_DEFER_CHECK", defer)
             prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=batch, order=order)
             try:
+                tile_regime = prob.ctx.kernel_regime(batch) == 2      # (a tuning knob may have switched the tile kernels off)
                 tl = (Nt + 1) * n
                 init = np.zeros((batch, tl))
                 init[:, :n] = u0 * (1.0 + 0.1 * np.arange(batch))[:, None]
@@ -339,7 +340,8 @@ def test_deferred_residual_test_reproduces_the_in_launch_one(hp, solvers, monkey
         assert np.array_equal(u0_, u1_) and np.array_equal(p0_, p1_)
         for a, b in ((lf0, lf1), (la0, la1)):
             # two to four launches, all needed: the case the deferral covers (dt = 1e-3: 3 x 12 or 4 x 10 sweeps)
-            assert 13 * (launches - 1) < int(a["solver_iters"].max()) <= 13 * (launches + (launches > 2)), a["solver_iters"].max()
+            if tile_regime:
+                assert 13 * (launches - 1) < int(a["solver_iters"].max()) <= 13 * (launches + (launches > 2)), a["solver_iters"].max()
             for k in a:
                 assert np.array_equal(a[k], b[k]), k
 
@@ -409,7 +411,7 @@ def test_walking_launches_with_a_batch(hp, solvers, monkeypatch):
         monkeypatch.setenv("FEMFCT_T4_WALKERS", "6")
         prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=2, order=hp.ORDER_VERTEX)
         try:
-            if walk == "1":
+            if walk == "1" and prob.ctx.uses_bandwidth_tiles(2):      # (a tuning knob may have switched the tile kernels off)
                 assert prob.ctx.patch_walkers(2) == 3 and prob.ctx.patch_walkers(1) == 6
             else:
                 assert prob.ctx.patch_walkers(2) == 0
