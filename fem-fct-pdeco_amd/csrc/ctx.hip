@@ -2,6 +2,7 @@
 #include "femfct_internal.h"
 #include "device_utils.h"
 
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -322,7 +323,27 @@ int femfct_create(femfct_ctx** out, int device_id) {
         delete ctx;
         return FEMFCT_ERR_HIP;
     }
+    // a rocprofiler-sdk tool in this process (rocprofv3 preloads it) intercepts every HSA queue: no graph replay then
+    // (femfct_ctx::graphs_blocked); RTLD_NOLOAD only asks whether the library is already resident
+    const char* pg = getenv("FEMFCT_PROFILER_GRAPHS");
+    if (!(pg && atoi(pg) != 0)) {
+        for (const char* name : {"librocprofiler-sdk.so.1", "librocprofiler-sdk.so"}) {
+            if (void* h = dlopen(name, RTLD_LAZY | RTLD_NOLOAD)) {
+                ctx->graphs_blocked = true;
+                dlclose(h);
+                break;
+            }
+        }
+    }
     *out = ctx;
+    return FEMFCT_OK;
+}
+
+// 1 while sweeps are replayed as hipGraphs, 0 while they are enqueued kernel by kernel (femfct_set_graphs(0), the
+// per-class profiling of bench.py, or a rocprofiler-sdk tool attached to the process)
+int femfct_graph_replay_active(const femfct_ctx* ctx, int* active_host) {
+    if (!ctx || !active_host) return FEMFCT_ERR_INVALID;
+    *active_host = (ctx->use_graphs && !ctx->prof_on && !ctx->graphs_blocked) ? 1 : 0;
     return FEMFCT_OK;
 }
 

@@ -68,6 +68,11 @@ struct femfct_ctx {
     std::map<int, int> kind_fail;   // largest Jacobi budget known to be too small, per kind
     std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
+    // hipGraph replay is held back while a rocprofiler-sdk tool intercepts the HSA queues (rocprofv3 --kernel-trace /
+    // --pmc): ROCm 7.2.0's interceptor walks a graph launch's AQL packet batch past the end of the 16384-packet ring when
+    // the batch straddles the wrap (host SIGSEGV inside librocprofiler-sdk.so; DESIGN.md section 9,
+    // tools/graph_intercept_probe.hip reproduces it without this library).  FEMFCT_PROFILER_GRAPHS=1 overrides.
+    bool graphs_blocked = false;
     int32_t steps_per_graph = 50;   // time steps captured per hipGraph in the trajectory drivers (only the last one moves the counters)
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
@@ -280,7 +285,7 @@ int femfct_enqueue_step(femfct_ctx* ctx, const double* A, const double* N, int32
 
 template <class F>
 int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue) {
-    if (!ctx->use_graphs || ctx->prof_on) return enqueue();
+    if (!ctx->use_graphs || ctx->prof_on || ctx->graphs_blocked) return enqueue();
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
         if (ctx->graphs.size() > 64) femfct_drop_graphs(ctx);

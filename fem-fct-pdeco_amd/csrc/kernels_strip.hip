@@ -983,7 +983,7 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
                                         bool fuse_end) {
     const int K = k_last - k_first + 1;
     if (K < 1 || K > 10) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "fused Chebyshev tail: %d iterations", K);
-    EndArgs e;
+    EndArgs e{};
     e.level = nullptr;
     if (fuse_end) {
         e.level = ctx->d_level; e.delta = ctx->rep_last ? ctx->end_req_delta * ctx->rep_total : 0;
@@ -1010,7 +1010,7 @@ int femfct_enqueue_tile_flux_limit(femfct_ctx* ctx, const double* D, const doubl
                                    VecRef out, int64_t out_bstride, int32_t batch, bool* fuse_end_io, int half_d) {
     const bool fuse_end = fuse_end_io && *fuse_end_io && ctx->N <= 512;
     if (fuse_end_io) *fuse_end_io = fuse_end;
-    EndArgs e;
+    EndArgs e{};
     e.level = nullptr;
     if (fuse_end) {
         e.level = ctx->d_level; e.delta = ctx->rep_last ? ctx->end_req_delta * ctx->rep_total : 0;

@@ -97,6 +97,7 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
             rc = step(budget, kbudget, std::min(per_graph, num_steps - k));
             if (rc != FEMFCT_OK) return rc;
         }
+        ctx->log_steps = ctx->log_batch = 0;      // no matching log while the copies are in flight / after a failure
         ctx->h_log.resize((size_t)num_steps * batch);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_log.data(), ctx->d_log, sizeof(StepCtl) * ctx->h_log.size(),
                                     hipMemcpyDeviceToHost, ctx->stream));

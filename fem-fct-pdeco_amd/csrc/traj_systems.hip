@@ -78,9 +78,11 @@ int check_common(femfct_ctx* ctx, int32_t num_steps, double dt, int32_t batch) {
 int terminal_diff(femfct_ctx* ctx, const double* target, const double* state, double* adj, int32_t num_steps,
                   int32_t batch) {
     const int64_t n = ctx->n, ts = (int64_t)(num_steps + 1) * n;
-    for (int32_t b = 0; b < batch; ++b)
-        femfct_enqueue_axpby(ctx, n, 1.0, target + (int64_t)b * n, -1.0, state + b * ts + (int64_t)num_steps * n,
-                             adj + b * ts + (int64_t)num_steps * n);
+    for (int32_t b = 0; b < batch; ++b) {
+        int rc = femfct_enqueue_axpby(ctx, n, 1.0, target + (int64_t)b * n, -1.0, state + b * ts + (int64_t)num_steps * n,
+                                      adj + b * ts + (int64_t)num_steps * n);
+        if (rc != FEMFCT_OK) return rc;
+    }
     return FEMFCT_OK;
 }
 
@@ -275,7 +277,8 @@ int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double
         return femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
     };
     auto begin = [&]() {
-        femfct_enqueue_axpby(ctx, wn, gam, ctx->d_M, 0.0, nullptr, ctx->d_trN);   // non_flux_mat = gamma*M (:588, shared)
+        int rn = femfct_enqueue_axpby(ctx, wn, gam, ctx->d_M, 0.0, nullptr, ctx->d_trN);   // non_flux_mat = gamma*M (:588, shared)
+        if (rn != FEMFCT_OK) return rn;
         return wsc ? (int)FEMFCT_OK : wind_ops(0);
     };
     auto step = [&](int budget, int kbudget, int reps) {
@@ -349,7 +352,7 @@ int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const doubl
         return femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trBase, 1);
     };
     auto begin = [&]() {
-        if (!wsc) wind_ops(0);
+        if (!wsc) { int rw = wind_ops(0); if (rw != FEMFCT_OK) return rw; }
         if (alltime) {
             for (int32_t b = 0; b < batch; ++b) {
                 HIP_TRY(ctx, hipMemsetAsync(p_traj + b * ts + (int64_t)num_steps * n, 0, sizeof(double) * n, ctx->stream));
@@ -357,7 +360,8 @@ int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const doubl
             }
             return FEMFCT_OK;
         }
-        terminal_diff(ctx, uhat_T, u_traj, p_traj, num_steps, batch);
+        int rt = terminal_diff(ctx, uhat_T, u_traj, p_traj, num_steps, batch);
+        if (rt != FEMFCT_OK) return rt;
         return terminal_diff(ctx, vhat_T, v_traj, q_traj, num_steps, batch);
     };
     auto step = [&](int budget, int kbudget, int reps) {

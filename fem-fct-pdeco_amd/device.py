@@ -125,6 +125,12 @@ class Context:
     def set_graphs(self, enable: bool):
         check(self.handle, lib.femfct_set_graphs(self.handle, int(bool(enable))))
 
+    def graph_replay_active(self) -> bool:
+        """False while sweeps are enqueued kernel by kernel: graphs off, per-class profiling, or rocprofv3 attached."""
+        v = C.c_int(0)
+        check(self.handle, lib.femfct_graph_replay_active(self.handle, C.byref(v)))
+        return bool(v.value)
+
     KERNEL_CLASSES = ("build_low", "jacobi", "dudt_rhs", "cheb", "flux", "limit", "assemble", "other")
 
     def set_profiling(self, enable: bool):

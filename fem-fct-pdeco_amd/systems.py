@@ -93,10 +93,22 @@ class PDESystems:
         self.n = self.ctx.n
         self._conv = {}
 
+    MAX_UNNAMED_WINDS = 8
+
     def convection(self, wind, name=None):
-        """assemble_sparse(dot(wind, grad(v))*u*dx) on the device (cached per wind)."""
+        """assemble_sparse(dot(wind, grad(v))*u*dx) on the device (cached per wind).
+
+        Named winds (the reference's parameter sets) stay for the life of the system.  A wind passed as a bare function
+        is keyed on the function object; a caller that builds a new lambda per call would otherwise add two device
+        matrices per call to a long-lived system, so only the MAX_UNNAMED_WINDS most recent ones are kept."""
         key = name if name is not None else wind       # the function object itself: stays alive, never aliases
         if key not in self._conv:
+            if name is None:
+                unnamed = [k for k in self._conv if callable(k)]
+                for old in unnamed[:max(0, len(unnamed) - self.MAX_UNNAMED_WINDS + 1)]:
+                    self.ctx.synchronize()
+                    for arr in self._conv.pop(old):
+                        arr.free()
             xq, yq = self.ctx.quad_points(self.mesh.n_cells)
             wx, wy = wind(xq, yq)
             A = self.ctx.assemble_convection(np.stack([wx, wy], axis=1).reshape(-1))
@@ -203,12 +215,29 @@ def _schnak_par():
     return [Du, Dv, c_b, gamma, omega1, omega2], wind
 
 
-def _wind_factors(wind_scale, num_steps, dt, t0=0.0):
-    """s(t_k), k = 0..num_steps, from a callable ``s(t)`` or an array; None stays None (stationary wind)."""
+def _wind_factors(wind_scale, num_steps, dt, t0=0.0, T=None):
+    """s(t_k), k = 0..num_steps, from a callable ``s(t)`` or an array; None stays None (stationary wind).
+
+    The time levels are ACCUMULATED the way the reference's loops do it, so that ``s`` sees the same floating-point
+    arguments: forward ``t = t0; t += dt`` per step (helpers.py:565-566); adjoint (``T`` given) ``t = T; t -= dt`` per
+    step (helpers.py:664, 679) -- ``t0 + k*dt`` differs from both in the last bits, amplified by 2 pi in sin(2 pi t)."""
     if wind_scale is None:
         return None
     if callable(wind_scale):
-        return np.array([float(wind_scale(t0 + k * dt)) for k in range(num_steps + 1)])
+        out = np.empty(num_steps + 1)
+        if T is None:
+            t = t0
+            out[0] = float(wind_scale(t))
+            for k in range(1, num_steps + 1):
+                t += dt
+                out[k] = float(wind_scale(t))
+        else:
+            t = T
+            out[num_steps] = float(wind_scale(t))
+            for k in range(num_steps - 1, -1, -1):
+                t -= dt
+                out[k] = float(wind_scale(t))
+        return out
     ws = np.asarray(wind_scale, dtype=np.float64).ravel()
     if ws.size != num_steps + 1:
         raise ValueError(f"wind_scale: {ws.size} values, expected num_steps + 1 = {num_steps + 1}")
@@ -257,7 +286,7 @@ def solve_adjoint_schnak_system(uk, vk, uhat_T, vhat_T, pk, qk, T, V, nodes, num
     try:
         p, q = B.up(pk), B.up(qk)
         S.ctx.schnak_adjoint(AwT, B.up(uk), B.up(vk), B.up(uhat_T), B.up(vhat_T), p, q, num_steps, dt, par,
-                             alltime=optim == "alltime", wind_scale=_wind_factors(wind_scale, num_steps, dt))
+                             alltime=optim == "alltime", wind_scale=_wind_factors(wind_scale, num_steps, dt, T=T))
         B.down(p, pk)
         B.down(q, qk)
     finally:

@@ -83,6 +83,11 @@ int         femfct_synchronize(femfct_ctx* ctx);
 void*       femfct_stream(femfct_ctx* ctx);                 /* hipStream_t */
 int         femfct_set_solver(femfct_ctx* ctx, int solver, double rel_tol, int max_iters);
 int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay of the step sequence (default on) */
+/* 1 while sweeps are replayed as hipGraphs.  0 after femfct_set_graphs(0), during per-class profiling, and while a
+ * rocprofiler-sdk tool (rocprofv3) is attached to the process: its HSA queue interceptor in ROCm 7.2.0 reads a graph
+ * launch's packet batch past the end of the queue ring (host SIGSEGV); FEMFCT_PROFILER_GRAPHS=1 overrides.  No reference
+ * counterpart (diagnostic). */
+int         femfct_graph_replay_active(const femfct_ctx* ctx, int* active_host);
 /* multi-sweep fusion of the Jacobi / Chebyshev kernels: row strips (any banded pattern) and 2-D tiles
  * (structured mesh in vertex order); both default on, results agree with the one-sweep kernels to the
  * solver tolerance.  For tests and tuning. */

@@ -10,6 +10,19 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+# crash diagnostics (FEMFCT_DUMP_MAPS=<file>): Python stack on a fatal signal and the process's address map, so that the
+# raw frame addresses a native fault handler prints can be resolved against the libraries afterwards
+import faulthandler
+faulthandler.enable()
+
+
+def dump_maps(tag):
+    path = os.environ.get("FEMFCT_DUMP_MAPS")
+    if path:
+        with open("/proc/self/maps") as f, open(f"{path}.{tag}", "w") as g:
+            g.write(f.read())
+
 hp = importlib.import_module("fem-fct-pdeco_amd")
 systems = importlib.import_module("fem-fct-pdeco_amd.systems")
 
@@ -48,6 +61,7 @@ t = timeit(lambda: ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0))
 kinfo = ctx.traj_krylov_info(Nt)
 print(f"Schnakenberg forward : {Nt / t:8.0f} steps/s  (species-solve iters max {kinfo['solver_iters'].max()}, jacobi sweeps max {ctx.traj_info(Nt)['solver_iters'].max()})")
 uh, vh = ctx.array(rng.random(n)), ctx.array(rng.random(n))
+dump_maps("before_schnak_adjoint")
 t = timeit(lambda: ctx.schnak_adjoint(AwT, u, v, uh, vh, p, q, Nt, dt, par))
 print(f"Schnakenberg adjoint : {Nt / t:8.0f} steps/s  (species-solve iters max {ctx.traj_krylov_info(Nt)['solver_iters'].max()})")
 
