@@ -142,7 +142,8 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
     size_t nv = (size_t)batch * ctx->n, nm = nv * ctx->W;
     int rc;
 #define A_(p, c) if ((rc = dev_alloc(ctx, &ctx->p, (c))) != FEMFCT_OK) return rc
-    A_(d_L, nm); A_(d_D, nm); A_(d_F, nm);
+    A_(d_L, nm + 1); A_(d_D, nm); A_(d_F, nm);     // d_L[nm] stays zero: read by k_strip_jacobi_pair_walk for a pair without an entry
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_L + nm, 0, sizeof(double), ctx->stream));
     A_(d_b, nv); A_(d_xa, nv); A_(d_xb, nv); A_(d_du, nv); A_(d_y0, nv); A_(d_y1, nv); A_(d_y2, nv);
     A_(d_rdu, nv); A_(d_rp, nv); A_(d_rm, nv);
     A_(d_part, (size_t)batch * 4 * FEMFCT_MAX_PARTIALS);
@@ -255,6 +256,13 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_T4_XCD")) ctx->t4_xcd = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_WALK")) ctx->t4_walk = atoi(e);   // 2: walk without the carry (measurement)
     if (const char* e = getenv("FEMFCT_T4_SNAKE")) ctx->t4_snake = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_T4_PAIR")) ctx->t4_pair = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_PAIR_SHAPE")) ctx->pair_shape = atoi(e);
+    if (getenv("FEMFCT_PAIR_TRACE") && !ctx->d_pair_trace) {
+        if (hipMalloc((void**)&ctx->d_pair_trace, sizeof(unsigned long long) * (FEMFCT_MAX_PARTIALS * 16 * 5 + 16)) == hipSuccess)
+            hipMemset(ctx->d_pair_trace, 0, sizeof(unsigned long long) * (FEMFCT_MAX_PARTIALS * 16 * 5 + 16));
+    }
+    if (const char* e = getenv("FEMFCT_PAIR_STAGGER_US")) ctx->pair_stagger = (int)(atof(e) * 100.0);
     if (const char* e = getenv("FEMFCT_DEFER_CHECK")) ctx->defer_check = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_INT")) ctx->t4_int = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_WALKERS")) { int v = atoi(e); if (v > 0) ctx->num_cus = v; }   // tests: walks on small meshes
@@ -351,6 +359,15 @@ int femfct_destroy(femfct_ctx* ctx) {
     if (!ctx) return FEMFCT_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->d_pair_trace) {
+        if (const char* path = getenv("FEMFCT_PAIR_TRACE")) {
+            std::vector<unsigned long long> h((size_t)FEMFCT_MAX_PARTIALS * 16 * 5 + 16);
+            if (hipMemcpy(h.data(), ctx->d_pair_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+        }
+        hipFree(ctx->d_pair_trace);
+        ctx->d_pair_trace = nullptr;
+    }
     femfct_release_pattern(ctx);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -410,7 +427,7 @@ int femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch) {
 
 int femfct_patch_walkers(const femfct_ctx* ctx, int32_t batch, int32_t sweeps) {
     if (!ctx || ctx->n <= 0 || batch < 1 || !femfct_tile4_wanted(ctx, batch) || femfct_single_patch(ctx, batch)) return 0;
-    return femfct_tile4_walkers(ctx, femfct_tile4_halo(ctx, sweeps > 0 ? sweeps : 36), batch);
+    return femfct_tile4_walkers(ctx, femfct_tile4_halo(ctx, sweeps > 0 ? sweeps : 36), batch, false);
 }
 
 // Share of the off-diagonal entries of the most recent low-order operator (batch member 0) that are non-zero, i.e.

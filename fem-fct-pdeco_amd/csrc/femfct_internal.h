@@ -83,6 +83,12 @@ struct femfct_ctx {
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int t4_snake = 1;           // walking Jacobi launches alternate their direction (FEMFCT_T4_SNAKE)
+    bool t4_pair = false;       // upwind rows as one value per opposing pair: k_strip8_jacobi_pair_walk, two workgroups per CU (FEMFCT_T4_PAIR)
+    int pair_stagger = 500;     // FEMFCT_PAIR_STAGGER_US * 100: ticks of the 100 MHz clock the second half of the pair walkers waits
+    unsigned long long* d_pair_trace = nullptr;   // FEMFCT_PAIR_TRACE=<file>: phase timestamps of the pair walkers, dumped at destroy
+    int pair_shape = 0;         // FEMFCT_PAIR_SHAPE: 0 = 10 rows x 6 waves, 1 = 8 x 6, 2 = 16 x 4, 3 = 8 x 8 (measurement)
+    bool pair_rows = false;     // set by femfct_run_sweep for the sweep in progress: its kind has only shown upwind rows so far
+    std::set<int> kind_fullrows;    // sweep kinds that raised FEMFCT_FLAG_ROW_PAIRS: full-row kernels from then on
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
     int t4_int = 1;             // Chebyshev on the mesh's mass matrix: interior patches by the two-workgroups-per-CU kernel (FEMFCT_T4_INT)
     int t4_walk = 1;            // 64-patch Jacobi: persistent workgroups walk down columns of patches, shared rows carried in LDS (FEMFCT_T4_WALK)
@@ -252,7 +258,8 @@ int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const 
 int femfct_tile4_init(femfct_ctx* ctx);
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
 int femfct_tile4_tiles(const femfct_ctx* ctx, int H = 8);
-int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch);   // 0: one workgroup per patch
+int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch, bool pair);   // 0: one workgroup per patch
+bool femfct_jacobi_pair_wanted(const femfct_ctx* ctx, int H, int32_t batch, bool have_lmask);
 int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps);
 bool femfct_single_patch(const femfct_ctx* ctx, int32_t batch);
 // launches and sweeps per launch the low-order solve of femfct_enqueue_step_mat will use for a budget

@@ -705,7 +705,8 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
         // sweeps per launch: the halo depth; a single patch runs the whole budget in one launch and stops by itself
         const int k4 = single ? budget : std::min(ctx->t4_k == 8 ? h4 : ctx->t4_k, h4);
         units = (budget + k4 - 1) / k4;
-        const int walkers = single ? 0 : femfct_tile4_walkers(ctx, h4, batch);
+        const bool pair4 = !single && femfct_jacobi_pair_wanted(ctx, h4, batch, lmask != nullptr);
+        const int walkers = single ? 0 : femfct_tile4_walkers(ctx, h4, batch, pair4);
         part_count = walkers > 0 ? walkers : big4 ? -1 : t4 * t4;
         ipu = k4;
         for (int s = 0; s < units; ++s)

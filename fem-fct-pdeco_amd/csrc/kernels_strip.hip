@@ -16,6 +16,7 @@
 #include "forms.h"
 
 #include <math.h>
+#include <type_traits>
 
 #define STRIP_T 1024
 
@@ -1555,6 +1556,15 @@ __device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned 
 #define STRIP4_NB(X, ABOVE, BELOW, r, s)                                                            \
     ((s) == 0 ? e_[r] : (s) == 1 ? ((r) < 3 ? e_[((r) + 1) & 3] : ea_) : (s) == 2 ? ((r) < 3 ? X[((r) + 1) & 3] : ABOVE) \
      : (s) == 3 ? w_[r] : (s) == 4 ? ((r) > 0 ? w_[((r) + 3) & 3] : wb_) : ((r) > 0 ? X[((r) + 3) & 3] : BELOW))
+// Accumulation order of the Jacobi rows in the 64-patch family: by opposing pairs -- (E, W), (NE, SW), (N, S).  The
+// upwind low-order operator has at most one non-zero entry per pair (d_ij = max(0, a_ij, a_ji) cancels the other),
+// so k_strip8_jacobi_pair_walk, which keeps ONE value per pair and selects the neighbour, adds the same non-zero
+// terms in the same order: the skipped terms are fma(-0, x, acc) = acc.  Same bits from every kernel of the family.
+#define STRIP4_ROW_FMAS(ACC, LV, X, ABOVE, BELOW, r)                                                \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                              \
+        ACC = fma(-LV[p_], STRIP4_NB(X, ABOVE, BELOW, r, p_), ACC);                                 \
+        ACC = fma(-LV[p_ + 3], STRIP4_NB(X, ABOVE, BELOW, r, p_ + 3), ACC);                         \
+    }
 
 // MODE 0: residual partials reduced by the next launch's workgroups; 1: more workgroups than in-kernel partials
 // (separate k_reduce_resid); 2: ONE workgroup covers the whole mesh and stops by itself (check_every > 0) -- its own
@@ -1681,8 +1691,7 @@ k_strip4_jacobi(int n, int N, const double* __restrict__ L_, const double* __res
         for (int r = 0; r < 4; ++r) {
             xn[r] = x[r];
             double acc = bv[r];
-#pragma unroll
-            for (int s = 0; s < W - 1; ++s) acc = fma(-lv[r][s], STRIP4_NB(x, above, below, r, s), acc);
+            STRIP4_ROW_FMAS(acc, lv[r], x, above, below, r);
             // no validity guard: a node at distance d from the patch border is exact after k <= d sweeps whatever
             // the nodes further out hold (they stay bounded: rows are diagonally dominant, outside rows are zero)
             if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
@@ -1872,8 +1881,7 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double acc = bv[r];
-#pragma unroll
-                for (int s = 0; s < W - 1; ++s) acc = fma(-lv[r][s], STRIP4_NB(x, above, below, r, s), acc);
+                STRIP4_ROW_FMAS(acc, lv[r], x, above, below, r);
                 if (k == K - 1 && g[r].owned) rmax = fmax(rmax, dg[r] * fabs(acc - x[r]));
                 xn[r] = acc;
             }
@@ -1885,6 +1893,351 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
         for (int r = 0; r < 4; ++r)
             if (g[r].owned) xout[g[r].i] = x[r];
     }
+    rmax = block_reduce(rmax, OpMax(), 0.0, smem);
+    if (threadIdx.x == 0) p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
+}
+
+// The walking Jacobi launch with ONE VALUE PER OPPOSING PAIR -- two workgroups to a compute unit.
+// A launch of k_strip4_jacobi_walk is a load phase at memory speed followed by register-resident sweeps, and with 115 VGPRs
+// only one 1024-thread workgroup fits a CU, so the two phases never overlap there.  For an upwind operator the six
+// off-diagonals of a row are three values: of each opposing pair (E, W), (NE, SW), (N, S) at most one entry is non-zero
+// (the zero mask k_build_low publishes says which).  This kernel keeps the non-zero value of each pair plus three select
+// bits: 12 instead of 18 registers per node.  A workgroup of NST waves owns a 64 x (R NST) patch, each thread R vertically
+// adjacent nodes (fewer strips: fewer LDS edge rows and barrier participants per node), sized so that TWO workgroups fit
+// a CU -- 6 waves x 10 rows at <= 168 VGPRs (three waves per SIMD), 75 KB of LDS -- each walking its own run of patches,
+// one's loads under the other's sweeps.  The FMAs run in the family's pair order (STRIP4_ROW_FMAS) with the neighbour
+// selected per lane: bit-identical to k_strip4_jacobi<0>.  Patches advance by T = 64 - 2H columns and TY = R NST - 2H rows.
+// A row with BOTH entries of a pair (eps > 0, or a user operator that is not upwind) cannot be represented: the kernel
+// raises FEMFCT_FLAG_ROW_PAIRS in the step record and the host repeats the sweep with the full-row kernels
+// (femfct_run_sweep); outside the trajectory sweeps the kernel is not used.
+constexpr int PAIR_CARRY_ROWS = 18;       // 2 * H, H <= 9 (the Jacobi launches: 36 sweeps = 4 x 9)
+constexpr int PAIR_POOL = 160;            // nodes of a patch with both entries of some pair (see below): 6 doubles each
+template <int R, int NST>
+__global__ void __launch_bounds__(64 * NST, (2 * NST + 3) / 4)
+k_strip_jacobi_pair_walk(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
+                         double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
+                         int g_build, double rel_tol, int H, const uint8_t* __restrict__ lmask, int npy, int npatch,
+                         int up, int64_t zero_index, int stagger_ticks, unsigned long long* __restrict__ trace) {
+    constexpr int W = 7, PR = R * NST;
+    __shared__ double top[2][NST][64], bot[2][NST][64];
+    __shared__ double carry[PAIR_CARRY_ROWS][6][64];        // three pair values, diagonal, b, input iterate
+    __shared__ uint8_t carry_nz[PAIR_CARRY_ROWS][64];
+    // Rows with BOTH entries of some pair (along the curves where a wind component changes sign: ~0.1 % of the rows for a
+    // smooth control) do not fit three values.  Their six scaled off-diagonals live here -- a patch-wide pool, each
+    // thread's nodes contiguous from `xstart` on in row order, found again by counting bits (no search, one register) --
+    // and the generic row update recomputes such a node's chain from them (all six FMAs, in the family's order).
+    __shared__ double pool_val[PAIR_POOL][6];
+    __shared__ unsigned pool_node[PAIR_POOL];       // node index | mask byte << 24 ... (index < 2^24 is not assumed: two words)
+    __shared__ uint8_t pool_mask[PAIR_POOL];
+    __shared__ int pool_cnt;
+    __shared__ double smem[32];
+    const int bz = blockIdx.z;
+    StepCtl* ctl = ctl_ + bz;
+    if (ctl->done) return;
+    double* p = part + (int64_t)bz * 4 * FEMFCT_MAX_PARTIALS;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    double bnorm;
+    if (launch == 0) {
+        bnorm = reduce_partials(p + 2 * FEMFCT_MAX_PARTIALS, g_build, OpMax(), 0.0, smem);
+        double rsmin = reduce_partials(p + 3 * FEMFCT_MAX_PARTIALS, g_build, OpMin(), INFINITY, smem);
+        if (wg == 0 && threadIdx.x == 0) {
+            ctl->bnorm = bnorm;
+            ctl->min_rowsum = rsmin;
+            if (!(rsmin > 0.0)) ctl->flags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+    } else {
+        bnorm = ctl->bnorm;
+        double rprev = reduce_partials(p + ((launch - 1) & 1) * FEMFCT_MAX_PARTIALS, nwg, OpMax(), 0.0, smem);
+        if (rprev <= rel_tol * bnorm) {
+            if (wg == 0 && threadIdx.x == 0) {
+                ctl->done = 1; ctl->parity = launch & 1; ctl->iters = launch * K; ctl->flags |= FEMFCT_FLAG_COARSE_ITERS;
+                ctl->resid = bnorm > 0.0 ? rprev / bnorm : 0.0;
+            }
+            return;
+        }
+    }
+    // Two workgroups share a CU.  Started together they load together and sweep together: nothing overlaps.  The second
+    // half of the grid (dispatched onto CUs that already hold one workgroup) is held back by about half a patch period,
+    // after which the two stay in opposite phases (both take the same time per patch).  Bounded wait; speed only.
+    if (stagger_ticks > 0 && wg >= nwg / 2) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < (int64_t)stagger_ticks) __builtin_amdgcn_s_sleep(16);
+    }
+    const int64_t moff = (int64_t)bz * W * n, voff = (int64_t)bz * n;
+    const double* L = L_ + moff;
+    const double* bvec = b_ + voff;
+    const uint8_t* msk = lmask + voff;
+    const double* xin = ((launch & 1) ? xb_ : xa_) + voff;
+    double* xout = ((launch & 1) ? xa_ : xb_) + voff;
+    const unsigned zo = (unsigned)(zero_index - moff);      // L[zo] == 0: read in place of a pair without an entry
+    const unsigned un = (unsigned)n;
+    const int st = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int T = T4_L - 2 * H, TY = PR - 2 * H;
+    const int q0 = (int)((int64_t)wg * npatch / nwg), q1 = (int)((int64_t)(wg + 1) * npatch / nwg);
+    double rmax = 0.0;
+    unsigned viol = 0;
+    const int lx0 = threadIdx.x & 63;
+    // first row index (patch-local) of this wave's strip; a wave takes its R rows either all from the carry or all from
+    // memory (the strip that straddles row 2H re-reads its carried rows)
+    const int ly0 = R * st;
+    const bool strip_in_carry = up ? ly0 >= TY : ly0 + R <= 2 * H;
+    // mask bytes of a patch's rows, four to a register (rows outside the mesh: node 0's, zeroed on use)
+    constexpr int NZW = (R + 3) / 4;
+    auto patch_masks = [&](int qq, unsigned (&out)[NZW], int lane) {
+        const int pxn = qq / npy, pyn = qq - pxn * npy;
+        const int gxn = pxn * T - H + lane, y0n = pyn * TY - H + ly0;
+        const int gxnc = (gxn >= 0 && gxn < N) ? gxn : 0;
+#pragma unroll
+        for (int w = 0; w < NZW; ++w) out[w] = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = y0n + r;
+            const int i = (gy >= 0 && gy < N) ? gy * N + gxnc : 0;
+            out[r >> 2] |= (unsigned)msk[i] << (8 * (r & 3));
+        }
+    };
+    unsigned nznext[NZW];
+    if (q1 > q0) patch_masks(up ? q1 - 1 : q0, nznext, lx0);
+    for (int j = 0; j < q1 - q0; ++j) {
+        const int q = up ? q1 - 1 - j : q0 + j;
+        int lx = lx0;
+        asm volatile("" : "+v"(lx));       // per-patch addresses are not loop invariants (see k_strip4_jacobi_walk)
+        const int px = q / npy, py = q - px * npy;
+        const bool cin = j > 0 && (up ? py + 1 < npy : py > 0);
+        const bool cout = j + 1 < q1 - q0 && (up ? py > 0 : py + 1 < npy);
+        // FEMFCT_PAIR_TRACE (tuning): 100 MHz timestamps of workgroup wg at patch start / rows in registers / after the
+        // carry barrier / after the sweeps / after the stores were issued -- 5 words per patch, 16 patches per walker
+        unsigned long long* tr = (trace && threadIdx.x == 0 && j < 16 && launch == 1) ? trace + ((int64_t)wg * 16 + j) * 5 : nullptr;
+        if (tr) tr[0] = __builtin_amdgcn_s_memrealtime();
+        const int x0 = px * T - H, y0 = py * TY - H + ly0;             // y0: mesh row of the strip's first row (uniform)
+        const int gx = x0 + lx;
+        const bool xin_mesh = gx >= 0 && gx < N;
+        const bool xowned = xin_mesh && lx >= H && lx < H + T;
+        const int gxc = xin_mesh ? gx : 0;
+        double v[R][3], dg[R], bv[R], x[R];
+        unsigned nzp[NZW];
+        if (cin && strip_in_carry) {
+            const int c0 = ly0 - (up ? TY : 0);
+#pragma unroll
+            for (int w = 0; w < NZW; ++w) nzp[w] = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) v[r][pr] = carry[c0 + r][pr][lx];
+                dg[r] = carry[c0 + r][3][lx];
+                bv[r] = carry[c0 + r][4][lx];
+                x[r] = carry[c0 + r][5][lx];
+                nzp[r >> 2] |= (unsigned)carry_nz[c0 + r][lx] << (8 * (r & 3));
+            }
+        } else {
+            // straight-line: 6 R loads in flight together, the entry of each pair chosen by the (prefetched) mask bits
+            unsigned ia[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int gy = y0 + r;
+                const bool row_in = gy >= 0 && gy < N;                 // uniform
+                ia[r] = row_in ? (unsigned)(gy * N + gxc) : 0u;
+                if (!(row_in && xin_mesh)) nznext[r >> 2] &= ~(0xffu << (8 * (r & 3)));
+            }
+#pragma unroll
+            for (int w = 0; w < NZW; ++w) nzp[w] = nznext[w];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned m = nzp[r >> 2] >> (8 * (r & 3));
+                dg[r] = L[ia[r]];
+                bv[r] = bvec[ia[r]];
+                x[r] = xin[ia[r]];
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) {
+                    const unsigned lo = (m >> pr) & 1u, hi = (m >> (pr + 3)) & 1u;
+                    const unsigned slot = lo ? (unsigned)(pr + 1) : (unsigned)(pr + 4);
+                    const unsigned off = (lo | hi) ? slot * un + ia[r] : zo;
+                    v[r][pr] = L[off];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int gy = y0 + r;
+                const bool inside = xin_mesh && gy >= 0 && gy < N;
+                const double rdg = 1.0 / dg[r];
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) v[r][pr] = inside ? v[r][pr] * rdg : 0.0;
+                bv[r] = inside ? bv[r] * rdg : 0.0;
+                x[r] = inside ? x[r] : 0.0;
+                dg[r] = inside ? dg[r] : 1.0;
+            }
+        }
+        if (tr) tr[1] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) pool_cnt = 0;        // (the previous patch's sweeps no longer read the counter, only their entries)
+        __syncthreads();                   // carry consumed; the previous patch's last sweep has left top / bot and the pool
+        if (tr) tr[2] = __builtin_amdgcn_s_memrealtime();
+        // this thread's rows with a double pair (one bit per row) and their records in the pool (rare: a dynamic loop that
+        // re-reads the row from memory, so that it needs no register array -- same operands, same bits as lv * rdg)
+        unsigned dm = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned m = nzp[r >> 2] >> (8 * (r & 3));
+            dm |= (((m & (m >> 3)) & 7u) ? 1u : 0u) << r;
+        }
+        // each such node gets a pool record: the thread only enters (node, mask) -- after the next barrier the whole
+        // workgroup fills the records' 6 scaled coefficients, one coefficient per thread, all loads in flight together
+        // (a thread filling its own records would wait two dependent memory round trips per node, up to R nodes in a row)
+        int xstart = 0;
+        if (dm) {
+            const int cnt = __popc(dm);
+            xstart = atomicAdd(&pool_cnt, cnt);
+            if (xstart + cnt > PAIR_POOL) { viol = 1; dm = 0; }
+            int e = xstart;
+            for (unsigned rest = dm; rest; rest &= rest - 1, ++e) {
+                const int r = __ffs(rest) - 1;
+                pool_node[e] = (unsigned)((y0 + r) * N + gxc);          // a double pair only exists inside the mesh
+                unsigned word = nzp[0];
+#pragma unroll
+                for (int w = 1; w < NZW; ++w) word = (r >> 2) == w ? nzp[w] : word;
+                pool_mask[e] = (uint8_t)(word >> (8 * (r & 3)));
+            }
+        }
+        if (cout) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int c = ly0 + r - (up ? 0 : TY);       // walking down the top 2H rows are kept, walking up the bottom ones
+                if (c < 0 || c >= 2 * H) continue;
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) carry[c][pr][lx] = v[r][pr];
+                carry[c][3][lx] = dg[r];
+                carry[c][4][lx] = bv[r];
+                carry[c][5][lx] = x[r];
+                carry_nz[c][lx] = (uint8_t)(nzp[r >> 2] >> (8 * (r & 3)));
+            }
+        }
+        // the next patch's mask bytes are requested before the sweeps: its row loads can then go out right behind this
+        // patch's stores instead of waiting a round trip for the masks
+        if (j + 1 < q1 - q0 && !(cout && strip_in_carry)) patch_masks(up ? q - 1 : q + 1, nznext, lx);
+        bot[0][st][lx] = x[0];             // edge rows of the input iterate for the first sweep
+        top[0][st][lx] = x[R - 1];
+        __syncthreads();
+        {
+            const int nrec = pool_cnt <= PAIR_POOL ? pool_cnt : 0;   // uniform: patches without a double pair (most) skip this; an overflowed pool (flagged: the sweep is void) holds stale records, which are not touched
+            if (nrec > 0) {
+                for (int t = threadIdx.x; t < nrec * 6; t += 64 * NST) {
+                    const int e = t / 6, sl = t - 6 * e;
+                    const unsigned i = pool_node[e], m = pool_mask[e];
+                    const double lvv = L[((m >> sl) & 1u) ? (unsigned)(sl + 1) * un + i : zo], dgv = L[i];
+                    pool_val[e][sl] = lvv * (1.0 / dgv);
+                }
+                __syncthreads();
+            }
+        }
+        // Which side each pair takes is a property of the wind direction, i.e. the same for whole regions: a wave whose R x 64
+        // nodes all take the same side of every pair (nodes without an entry in a pair do not care: their value is 0) runs a
+        // sweep loop specialised for that pattern P (bit p: pair p takes W / SW / S) -- no selects, and only the lane shifts
+        // the pattern needs (one per row for E + NE and for W + SW, two otherwise).  Other waves run the generic loop (P = 8).
+        unsigned fold = 0;
+#pragma unroll
+        for (int w = 0; w < NZW; ++w) fold |= nzp[w];
+        fold |= fold >> 16;
+        fold |= fold >> 8;
+        int pat = 0;
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const bool lo_any = __ballot((fold >> pr) & 1u) != 0, hi_any = __ballot((fold >> (pr + 3)) & 1u) != 0;
+            pat |= (lo_any && hi_any) ? 8 : (hi_any ? (1 << pr) : 0);
+        }
+        pat = __builtin_amdgcn_readfirstlane(pat > 7 ? 8 : pat);
+        if (trace && launch == 1 && (threadIdx.x & 63) == 0) atomicAdd(trace + (int64_t)FEMFCT_MAX_PARTIALS * 16 * 5 + pat, 1ull);   // FEMFCT_PAIR_TRACE: waves per pattern
+        auto sweeps = [&](auto PC) {
+            constexpr int P = decltype(PC)::value;
+            bool hsel[R][3];
+            if constexpr (P == 8) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        const unsigned m = nzp[r >> 2] >> (8 * (r & 3));
+                        hsel[r][pr] = ((m >> (3 + pr)) & 1u) != 0 && ((m >> pr) & 1u) == 0;
+                    }
+            }
+            // One barrier per sweep, placed so that it is covered: a sweep first updates the strip's two EDGE rows (they need
+            // the neighbouring strips' edge rows of the previous sweep, read from LDS), stores the new edge rows for the
+            // next sweep, and only then updates its interior rows (own registers only) -- the LDS stores and the arrival of
+            // the other waves at the barrier happen under the interior rows' arithmetic.
+            auto row = [&](int r, double xr, double xs, double xn) {     // xs / xn: OLD values of the S / N neighbour
+                double acc = bv[r];
+                if constexpr (P == 8) {
+                    // generic row: the neighbour of each pair's entry selected per lane.  A node with a double pair (rare;
+                    // lanes without one skip the block) takes its whole chain from its pool record instead.  The index
+                    // passes through an empty asm so that these loop-invariant LDS reads stay inside the sweeps.
+                    const double ev = dpp_from_next(xr), wv = dpp_from_prev(xr), ne = dpp_from_next(xn), sw = dpp_from_prev(xs);
+                    acc = fma(-v[r][0], hsel[r][0] ? wv : ev, acc);      // (E, W)
+                    acc = fma(-v[r][1], hsel[r][1] ? sw : ne, acc);      // (NE, SW)
+                    acc = fma(-v[r][2], hsel[r][2] ? xs : xn, acc);      // (N, S)
+                    if ((dm >> r) & 1u) {
+                        int idx = xstart + __popc(dm & ((1u << r) - 1u));
+                        asm volatile("" : "+v"(idx));
+                        const double* c = pool_val[idx];
+                        double a2 = bv[r];
+                        a2 = fma(-c[0], ev, a2); a2 = fma(-c[3], wv, a2);
+                        a2 = fma(-c[1], ne, a2); a2 = fma(-c[4], sw, a2);
+                        a2 = fma(-c[2], xn, a2); a2 = fma(-c[5], xs, a2);
+                        acc = a2;
+                    }
+                } else {
+                    acc = fma(-v[r][0], (P & 1) ? dpp_from_prev(xr) : dpp_from_next(xr), acc);
+                    acc = fma(-v[r][1], (P & 2) ? dpp_from_prev(xs) : dpp_from_next(xn), acc);
+                    acc = fma(-v[r][2], (P & 4) ? xs : xn, acc);
+                }
+                return acc;
+            };
+            for (int k = 0; k < K; ++k) {
+                const int par = k & 1;
+                const bool last = k == K - 1;
+                const double above = (st < NST - 1) ? bot[par][st + 1][lx] : 0.0;
+                const double below = (st > 0) ? top[par][st - 1][lx] : 0.0;
+                double xo[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) xo[r] = x[r];
+                x[0] = row(0, xo[0], below, xo[1]);
+                x[R - 1] = row(R - 1, xo[R - 1], xo[R - 2], above);
+                if (!last) {
+                    bot[par ^ 1][st][lx] = x[0];
+                    top[par ^ 1][st][lx] = x[R - 1];
+                }
+#pragma unroll
+                for (int r = 1; r < R - 1; ++r) {
+                    x[r] = row(r, xo[r], xo[r - 1], xo[r + 1]);
+                    if (P == 8 && (r & 1)) __builtin_amdgcn_sched_barrier(0);   // generic loop: keep the live lane shifts few
+                }
+                if (last) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int ly = ly0 + r, gy = y0 + r;
+                        if (xowned && ly >= H && ly < H + TY && gy >= 0 && gy < N) rmax = fmax(rmax, dg[r] * fabs(x[r] - xo[r]));
+                    }
+                } else {
+                    __syncthreads();
+                }
+            }
+        };
+        switch (pat) {
+            case 0: sweeps(std::integral_constant<int, 0>{}); break;
+            case 1: sweeps(std::integral_constant<int, 1>{}); break;
+            case 2: sweeps(std::integral_constant<int, 2>{}); break;
+            case 3: sweeps(std::integral_constant<int, 3>{}); break;
+            case 4: sweeps(std::integral_constant<int, 4>{}); break;
+            case 5: sweeps(std::integral_constant<int, 5>{}); break;
+            case 6: sweeps(std::integral_constant<int, 6>{}); break;
+            case 7: sweeps(std::integral_constant<int, 7>{}); break;
+            default: sweeps(std::integral_constant<int, 8>{}); break;
+        }
+        if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int ly = ly0 + r, gy = y0 + r;
+            if (xowned && ly >= H && ly < H + TY && gy >= 0 && gy < N) xout[gy * N + gx] = x[r];
+        }
+        if (tr) tr[4] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (viol) atomicOr(&ctl->flags, FEMFCT_FLAG_ROW_PAIRS);     // a patch with more double pairs than the pool holds
     rmax = block_reduce(rmax, OpMax(), 0.0, smem);
     if (threadIdx.x == 0) p[(launch & 1) * FEMFCT_MAX_PARTIALS + wg] = rmax;
 }
@@ -2313,12 +2666,42 @@ int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
 // Walkers per batch member of the walking Jacobi launch (0: one workgroup per patch).  One 1024-thread workgroup fits
 // a CU, so a launch keeps num_cus of them busy: with at least two patches per walker the carried rows pay, below that
 // hardware dispatch of one workgroup per patch fills the chip better.
-int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch) {
+// pair: the launch is k_strip_jacobi_pair_walk<PAIR_R, PAIR_NST> -- two such workgroups fit a CU, so twice the walkers
+// (but still at least two patches per walker, and the same regime boundary as the 1024-thread walk).
+// shape = rows per thread x waves per workgroup (FEMFCT_PAIR_SHAPE, a measurement knob; 0 is the product's)
+static void pair_shape(const femfct_ctx* ctx, int* R, int* NST) {
+    switch (ctx->pair_shape) {
+        case 1: *R = 8; *NST = 6; break;
+        case 6: *R = 12; *NST = 4; break;
+        case 7: *R = 14; *NST = 4; break;
+        case 8: *R = 16; *NST = 4; break;
+        case 3: *R = 8; *NST = 8; break;
+        case 4: *R = 7; *NST = 8; break;
+        case 5: *R = 6; *NST = 8; break;
+        default: *R = 10; *NST = 6; break;
+    }
+}
+static int pair_tiles_y(const femfct_ctx* ctx, int H) {
+    int R, NST;
+    pair_shape(ctx, &R, &NST);
+    const int TY = R * NST - 2 * H;
+    return (ctx->N + TY - 1) / TY;
+}
+int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch, bool pair) {
     if (!ctx->t4_walk || !ctx->t4_dpp || 2 * H > WALK_CARRY_ROWS) return 0;
     const int t = femfct_tile4_tiles(ctx, H);
     const int w = std::min(ctx->num_cus / std::max(1, (int)batch), FEMFCT_MAX_PARTIALS);
     if (w < 1 || (int64_t)t * t < 2 * (int64_t)w) return 0;
+    if (pair) return (int)std::min<int64_t>(std::min(2 * w, FEMFCT_MAX_PARTIALS), (int64_t)t * pair_tiles_y(ctx, H) / 2);
     return w;
+}
+
+// the pair-compact walking launch applies: asked for by the sweep driver (ctx->pair_rows: a kind of sweep whose rows
+// have so far all been upwind rows), zero masks in use, walking regime
+bool femfct_jacobi_pair_wanted(const femfct_ctx* ctx, int H, int32_t batch, bool have_lmask) {
+    if (!(ctx->t4_pair && ctx->pair_rows && have_lmask && ctx->t4_walk == 1 && 2 * H <= PAIR_CARRY_ROWS && ctx->t4_k == 8)) return false;
+    if ((uint64_t)ctx->ws_batch * ctx->W * (uint64_t)ctx->n + 1 >= (1ull << 32)) return false;   // 32-bit element offsets into L
+    return femfct_tile4_walkers(ctx, H, batch, false) > 0;
 }
 
 int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* b, double* xa, double* xb, int launch,
@@ -2328,8 +2711,26 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     dim3 grid(t, t, batch);
     const size_t lds = (size_t)2 * T4_BUF * 8;
     femfct_prof_begin(ctx, KC_JACOBI);
-    const int walkers = check_every > 0 ? 0 : femfct_tile4_walkers(ctx, H, batch);
-    if (walkers > 0) {
+    const bool pair = check_every <= 0 && femfct_jacobi_pair_wanted(ctx, H, batch, lmask != nullptr);
+    const int walkers = check_every > 0 ? 0 : femfct_tile4_walkers(ctx, H, batch, pair);
+    if (pair) {
+        const int npy = pair_tiles_y(ctx, H);
+#define PAIR_LAUNCH(RR, NN)                                                                                              \
+        hipLaunchKernelGGL((k_strip_jacobi_pair_walk<RR, NN>), dim3(walkers, 1, batch), dim3(64 * NN), 0, ctx->stream,    \
+                           ctx->n, ctx->N, L, b, xa, xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, lmask, npy, \
+                           t * npy, ctx->t4_snake ? (launch & 1) : 0, (int64_t)ctx->ws_batch * ctx->W * ctx->n, ctx->pair_stagger, ctx->d_pair_trace)
+        switch (ctx->pair_shape) {
+            case 1: PAIR_LAUNCH(8, 6); break;
+            case 6: PAIR_LAUNCH(12, 4); break;
+            case 7: PAIR_LAUNCH(14, 4); break;
+            case 8: PAIR_LAUNCH(16, 4); break;
+            case 3: PAIR_LAUNCH(8, 8); break;
+            case 4: PAIR_LAUNCH(7, 8); break;
+            case 5: PAIR_LAUNCH(6, 8); break;
+            default: PAIR_LAUNCH(10, 6); break;
+        }
+#undef PAIR_LAUNCH
+    } else if (walkers > 0) {
         hipLaunchKernelGGL(k_strip4_jacobi_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa,
                            xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, ctx->t4_stagger, lmask, t, t * t, ctx->t4_walk == 1 ? 1 : 0, ctx->t4_snake ? (launch & 1) : 0);
     } else if (ctx->t4_dpp) {
@@ -2369,7 +2770,7 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
     const int H = single ? T4_H : femfct_tile4_halo(ctx, k_last - k_first + 1);
     const int per_launch = single ? ((io_in && io_in->om_dev) ? k_last - k_first + 1 : 24) : H;   // by-value omega table: 24
     const int t = femfct_tile4_tiles(ctx, H);
-    const int walkers = single ? 0 : femfct_tile4_walkers(ctx, H, batch);
+    const int walkers = single ? 0 : femfct_tile4_walkers(ctx, H, batch, false);
     // patches 1 .. n_int (per direction) lie wholly in the mesh interior: (p + 1) T + H <= N - 1
     const int n_int = (single || !ctx->t4_int) ? 0 : std::max(0, (ctx->N - 1 - H) / (T4_L - 2 * H) - 1);
     const size_t lds = (size_t)3 * T4_BUF * 8;

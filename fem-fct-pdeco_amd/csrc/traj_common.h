@@ -38,6 +38,7 @@ static inline int femfct_round_kry_budget(const femfct_ctx* ctx, int b) {
 template <class F>
 int femfct_run_graph_reps(femfct_ctx* ctx, femfct_ctx::GraphKey key, int reps, int delta, F&& enqueue_one) {
     key.push_back(key_bits((int32_t)reps));
+    key.push_back(key_bits((int32_t)ctx->pair_rows));     // a different Jacobi kernel is captured
     // delta: the time-level step of this kind of sweep (+1 forward, -1 adjoint).  Step r is enqueued with its level
     // offset baked into every level-indirected reference (lref, MatRef::level_off); the device counters move once, in
     // the last step of the graph -- no per-step ticket / counter update on the critical path of the other R - 1 steps.
@@ -71,9 +72,12 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
     if (!ctx->kind_budget.count(kind)) ctx->kind_budget[kind] = 48;
     struct RestoreSolver {       // the effective solver is per kind of sweep; the user's choice comes back on every exit
         femfct_ctx* c;
-        ~RestoreSolver() { c->solver = c->solver_user; }
+        ~RestoreSolver() { c->solver = c->solver_user; c->pair_rows = false; }
     } restore_solver{ctx};
     for (;;) {
+        // bandwidth regime: rows of an upwind operator as one value per opposing pair (k_strip8_jacobi_pair_walk), until a
+        // sweep of this kind shows a row that is not one (FEMFCT_FLAG_ROW_PAIRS below)
+        ctx->pair_rows = !ctx->kind_fullrows.count(kind);
         // a kind whose operator lies outside the scheme's dt restriction (Jacobi does not contract: the reference's
         // spsolve does not care, helpers.py:1782) is solved with Jacobi-preconditioned BiCGStab from then on
         ctx->solver = ctx->kind_low_bicg.count(kind) ? FEMFCT_SOLVER_BICGSTAB : ctx->solver_user;
@@ -112,8 +116,15 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         ctx->log_steps = num_steps;
         ctx->log_batch = batch;
         int worst = 0, kworst = 0;
-        bool short_budget = false, kshort = false, coarse = false;
+        bool short_budget = false, kshort = false, coarse = false, not_pairs = false;
         double worst_res = 0.0, kworst_res = 0.0;
+        for (const StepCtl& c : ctx->h_log) not_pairs = not_pairs || (c.flags & FEMFCT_FLAG_ROW_PAIRS);
+        if (not_pairs && !getenv("FEMFCT_PAIR_FORCE")) {             // what the pair-compact launches computed is void: repeat with the full-row kernels
+            if (getenv("FEMFCT_DEBUG")) fprintf(stderr, "[femfct] sweep kind %d: rows with both entries of a pair -> full-row Jacobi launches\n", kind);
+            ctx->kind_fullrows.insert(kind);
+            ctx->log_steps = ctx->log_batch = 0;
+            continue;
+        }
         for (const StepCtl& c : ctx->h_log) {
             if (c.iters > worst) coarse = (c.flags & FEMFCT_FLAG_COARSE_ITERS) != 0;
             worst = std::max(worst, c.iters);

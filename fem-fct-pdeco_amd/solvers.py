@@ -214,7 +214,10 @@ def pgd_solidbody(prob: SolidBodyDrift, u0, uhat, c0, beta, c_lower, c_upper, it
     cB, uB, ckB = ctx.zeros(B * tl), ctx.zeros(B * tl), ctx.zeros(B * tl)
     for k in range(B):                                  # level 0 of every trial trajectory = the initial condition
         uB.copy_from(u, n, dst_off=k * tl)
-    hist = dict(cost=[], armijo_k=[], step=[], rel_change=[])
+    # armijo_margin: per iteration, for every trial the sequential search looks at, the distance of the Armijo test from
+    # its threshold relative to the cost, (J_trial - J_k + gam/s ||c_inc - c||^2_Q) / |J_k|  (> 0: rejected).  A margin of
+    # the size of the solver tolerance would mean that two faithful implementations may decide differently.
+    hist = dict(cost=[], armijo_k=[], step=[], rel_change=[], armijo_margin=[])
     if alltime:
         u.copy_from(uh, tl - n, dst_off=n, src_off=n)      # uk = np.copy(uhat_all), level 0 = u0
     else:
@@ -235,30 +238,36 @@ def pgd_solidbody(prob: SolidBodyDrift, u0, uhat, c0, beta, c_lower, c_upper, it
                 prob.forward(cB, uB, batch=B)
                 J = prob.cost(uB, uhB, cB, beta, optim, batch=B)
                 stat = ctx.l2_norm_sq_Q(cB, ckB, Nt, dt, batch=B)
+                margins = []
                 for k, s in enumerate(svals):
                     accepted = k
+                    margins.append((float(J[k]) - J_k + gam / s * float(stat[k])) / abs(J_k))
                     if not (J[k] - J_k > -gam / s * stat[k]):
                         break
                 J_acc = float(J[accepted])
                 c_prev.copy_from(cB, tl, src_off=accepted * tl)
                 u.copy_from(uB, tl, src_off=accepted * tl)
             else:
+                margins = []
                 for k, s in enumerate(svals):
                     accepted = k
                     ctx.project_control(c, s, d, c_lower, c_upper, cB, tl)
                     prob.forward(cB, uB, batch=1)
                     J_acc = float(prob.cost(uB, uh, cB, beta, optim, batch=1)[0])
                     stat = float(ctx.l2_norm_sq_Q(cB, c, Nt, dt)[0])
+                    margins.append((J_acc - J_k + gam / s * stat) / abs(J_k))
                     if not (J_acc - J_k > -gam / s * stat):
                         break
                 c_prev.copy_from(cB, tl)
                 u.copy_from(uB, tl)
             hist["cost"].append(J_acc)
+            hist["armijo_margin"].append(margins)
             hist["armijo_k"].append(accepted + 1)
             hist["step"].append(svals[accepted])
             hist["rel_change"].append(abs(J_k - J_acc) / abs(J_k))
             if tol is not None and hist["rel_change"][-1] < tol:
                 break
+        hist["armijo_margin_min"] = min((abs(m) for ms in hist["armijo_margin"] for m in ms), default=None)
         return u.download(), p.download(), c_prev.download(), hist
     finally:
         for a in (u, p, d, c, rhs, c_prev, uh, uhB, cB, uB, ckB):

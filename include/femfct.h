@@ -55,6 +55,9 @@ typedef struct femfct_ctx femfct_ctx;
                                          the "3: False" diagnostic of helpers.py:1796-1799 */
 #define FEMFCT_FLAG_SOLVER_BUDGET  2  /* sweep/iteration budget exhausted before tolerance */
 #define FEMFCT_FLAG_COARSE_ITERS   4  /* solver_iters is an upper bound (whole fused launches), not the exact count */
+#define FEMFCT_FLAG_ROW_PAIRS      16 /* internal to a trajectory sweep: the pair-compact Jacobi launch met a row with both
+                                         entries of an opposing stencil pair; the sweep is repeated with full rows, so
+                                         a caller never sees this flag after a successful call */
 #define FEMFCT_FLAG_CHEBYSHEV      8  /* species solve done by the Chebyshev iteration; solver_iters is the count that
                                          meets tolerance/10 at its asymptotic rate (the next sweep's budget) */
 

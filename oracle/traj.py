@@ -342,6 +342,51 @@ def solidbody_descent_direction(sb: SolidBody, ck, uk, pk, beta, nodes, num_step
     return dk
 
 
+def solidbody_pgd_loop(sb: SolidBody, u0, uhat, c0, beta, c_lower, c_upper, iters, nodes, num_steps, dt,
+                       gam=1e-4, s0=1.0, max_armijo=10, optim="finaltime"):
+    """The projected-gradient loop of advection_solidbody_FCT_PDECO_finaltime_Garvie.py:164-330 (optim="finaltime":
+    uhat = target at T) and ..._alltime_Garvie.py:164-340 (optim="alltime": uhat = target trajectory), with the inline
+    Armijo search of :259-317: trial steps s0 / 2^k, the first with J(c_inc) - J_k <= -gam/s ||c_inc - c||^2_Q is taken,
+    else the last.  Returns (u, p, c, history); history["armijo_margin"][it][k] =
+    (J_trial - J_k + gam/s ||c_inc - c||^2_Q) / |J_k| for every trial looked at (> 0: rejected)."""
+    from .fct import cost_functional, l2_norm_sq_Q
+    n, Nt = nodes, num_steps
+    tl = (Nt + 1) * n
+    M = sb.cm.M
+    uhat = np.asarray(uhat, dtype=np.float64)
+    uk = np.zeros(tl)
+    uk[:n] = u0
+    if optim == "alltime":
+        uk[n:] = uhat[n:]                       # uk = np.copy(uhat_all), level 0 = u0
+    else:
+        uk[Nt * n:] = uhat                      # uk[num_steps*nodes:] = uhat_T (finaltime.py:146)
+    c_prev = np.array(c0, dtype=np.float64)
+    pk = np.zeros(tl)
+    hist = dict(cost=[], armijo_k=[], armijo_margin=[])
+    for _ in range(iters):
+        pk = solidbody_adjoint(sb, c_prev, uk, uhat, np.zeros(tl), n, Nt, dt, optim=optim)
+        dk = solidbody_descent_direction(sb, c_prev, uk, pk, beta, n, Nt)
+        ck = np.clip(c_prev + s0 * dk, c_lower, c_upper)
+        solidbody_forward(sb, ck, uk, n, Nt, dt)
+        J_k = cost_functional(uk, uhat, ck, Nt, dt, M, beta, optim)
+        margins = []
+        for k in range(max_armijo):
+            s = s0 * (1 / 2 ** k)
+            c_inc = np.clip(ck + s * dk, c_lower, c_upper)
+            solidbody_forward(sb, c_inc, uk, n, Nt, dt)
+            J = cost_functional(uk, uhat, c_inc, Nt, dt, M, beta, optim)
+            stat = l2_norm_sq_Q(c_inc - ck, Nt, dt, M)
+            margins.append((J - J_k + gam / s * stat) / abs(J_k))
+            if not (J - J_k > -gam / s * stat):
+                break
+        hist["cost"].append(J)
+        hist["armijo_k"].append(k + 1)
+        hist["armijo_margin"].append(margins)
+        c_prev = c_inc
+    hist["armijo_margin_min"] = min(abs(m) for ms in hist["armijo_margin"] for m in ms)
+    return uk, pk, c_prev, hist
+
+
 # ---------------------------------------------------------------------------
 # linear advection-diffusion with a distributed source control and a manufactured solution
 #   advection_FCT_PDECO_alltime_exact.py (config C1's parameter set)

@@ -127,6 +127,92 @@ def test_c2_solidbody_81x81_250_steps_forward_adjoint(hp, solvers, order):
         prob.close()
 
 
+def _pgd_vs_oracle(hp, solvers, sb, prob, u0, uhat, c0, beta, iters, max_armijo, optim, n, Nt, dt, v2d, name):
+    """Device PGD loop (speculative and sequential) against oracle.traj.solidbody_pgd_loop on the same data: identical
+    Armijo decisions, costs to 1e-9, every Armijo margin reproduced, final control / state to 1e-7, and the decisions
+    far from their thresholds compared with the 1e-12 parity of a single cost evaluation."""
+    from oracle import traj as otraj
+    gam, s0, lo, hi = 1e-4, 1.0, 0.0, 5.0
+    u_o, _, c_o, h_o = otraj.solidbody_pgd_loop(sb, u0, uhat, c0, beta, lo, hi, iters, n, Nt, dt, gam, s0, max_armijo, optim)
+
+    def to_dev(x):
+        return x.reshape(-1, n)[:, v2d].reshape(-1)
+
+    def from_dev(x):
+        out = np.empty_like(x.reshape(-1, n))
+        out[:, v2d] = x.reshape(-1, n)
+        return out.reshape(-1)
+
+    pgd = solvers.pgd_solidbody_finaltime if optim == "finaltime" else solvers.pgd_solidbody_alltime
+    res = {}
+    for spec in (True, False):
+        u_d, _, c_d, h_d = pgd(prob, to_dev(u0), to_dev(uhat), to_dev(c0), beta, lo, hi, iters, gam, s0, max_armijo, spec)
+        assert h_d["armijo_k"] == h_o["armijo_k"], (h_d["armijo_k"], h_o["armijo_k"])
+        assert np.allclose(h_d["cost"], h_o["cost"], rtol=1e-9, atol=0)
+        for ms_d, ms_o in zip(h_d["armijo_margin"], h_o["armijo_margin"]):
+            assert len(ms_d) == len(ms_o) and np.allclose(ms_d, ms_o, rtol=1e-4, atol=1e-12)
+        ec, eu = rel(from_dev(c_d), c_o) if np.linalg.norm(c_o) > 0 else np.abs(c_d).max(), rel(from_dev(u_d), u_o)
+        assert ec < 1e-7 and eu < 1e-7
+        assert h_d["armijo_margin_min"] > 1e-11            # >> the 1e-12 agreement of one cost evaluation
+        res[spec] = (ec, eu, h_d)
+    assert h_o["armijo_margin_min"] > 1e-11
+    _report(name, c_rel_l2=res[True][0], u_rel_l2=res[True][1], armijo_margin_min=h_o["armijo_margin_min"])
+    print(f"[fullsize] {name}: armijo_k {h_o['armijo_k']}, cost {h_o['cost']}")
+    return h_o
+
+
+def test_c2_pgd_loop_81x81_250_steps_vs_oracle(hp, solvers):
+    """BASELINE configs[1] asks for "PGD 20 iters": the LOOP of advection_solidbody_FCT_PDECO_finaltime.py:160-262 /
+    ..._finaltime_Garvie.py:259-317 at the config's own size -- 81 x 81, dt 1e-3, 250 + 250 steps per sweep, the
+    reference's target data/solidbody_t0.25_u.csv, beta = 1, box [0, 5], c0 = 1 (bench.py's pgd_c2) -- two iterations
+    with four Armijo trials each, speculative and sequential, against the oracle loop (~ 10 oracle sweeps)."""
+    from oracle import traj as otraj
+    from helpers_golden import load
+    a1, a2, deltax, dt, Nt, om = -1.0, 1.0, 0.1 / 2 / 2, 1e-3, 250, np.pi / 40
+    nc = round((a2 - a1) / deltax)
+    omesh, asm = _oracle(a1, a2, nc)
+    n = omesh.nodes
+    v2d = omesh.vertex_to_dof
+    u0 = np.zeros(n)
+    u0[v2d] = _slotted_disc(a1, a2, deltax)
+    uhat = load("solidbody_t0.25_u.npz")["u"]
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(a1, a2, nc), Nt, dt, om=om, order=hp.ORDER_VERTEX)
+    try:
+        h = _pgd_vs_oracle(hp, solvers, otraj.SolidBody(asm, om=om), prob, u0, uhat, np.ones((Nt + 1) * n), 1.0, 2, 4,
+                           "finaltime", n, Nt, dt, v2d, "C2 PGD loop 81^2 x 250")
+        assert h["armijo_k"] == [4, 4]          # the reference's behaviour on this data: both searches exhaust (DESIGN 5)
+    finally:
+        prob.close()
+
+
+def test_c5_pgd_loop_81x81_100_steps_mixed_decisions_vs_oracle(hp, solvers):
+    """The all-time loop of config 5 (advection_solidbody_FCT_PDECO_alltime.py:43-74 set-up, ..._alltime_Garvie.py loop) at
+    beta = 1e-3: the first search exhausts, the later ones accept at the first trial -- accept AND reject decisions at
+    the config's size, speculative and sequential, against the oracle loop."""
+    from oracle import traj as otraj
+    a1, a2, dx, dt, Nt, beta = -1.0, 1.0, 0.025, 1e-3, 100, 1e-3
+    nc = round((a2 - a1) / dx)
+    omesh, asm = _oracle(a1, a2, nc)
+    n = omesh.nodes
+    v2d = omesh.vertex_to_dof
+    X = np.arange(a1, a2 + dx, dx)
+    X, Y = np.meshgrid(X, X)
+    u0 = np.zeros(n)
+    u0[v2d] = np.exp(-20 * ((X + 2 / 3) ** 2 + 5 * (Y + 5 / 6) ** 2)).reshape(-1)
+    tl = (Nt + 1) * n
+    sb = otraj.SolidBody(asm, rot_scale=0.0)
+    uhat = np.zeros(tl)
+    uhat[:n] = u0
+    otraj.solidbody_forward(sb, 2.0 * np.ones(tl), uhat, n, Nt, dt)
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(a1, a2, nc), Nt, dt, rot_scale=0.0, order=hp.ORDER_VERTEX)
+    try:
+        h = _pgd_vs_oracle(hp, solvers, sb, prob, u0, uhat, np.ones(tl), beta, 3, 6, "alltime", n, Nt, dt, v2d,
+                           "C5 PGD loop 81^2 x 100, beta 1e-3")
+        assert h["armijo_k"] == [6, 1, 1]
+    finally:
+        prob.close()
+
+
 def test_c3_schnakenberg_41x41_200_steps_forward_adjoint(hp):
     """Schnakenberg system at dx = 0.025, dt = 5e-4, T = 0.1: final-time adjoint (HEAD driver,
     Schnak_FCT_PDECO_refactored.py) and the all-time misfit of the config-3 script."""
@@ -350,13 +436,14 @@ def test_c1_exact_solution_parameter_set_11x11_100_steps(hp, solvers):
 def test_mimura_named_grid_129x129_forward(hp, monkeypatch):
     """BASELINE configs[3] names chemotaxis_mimura_FCT_PGD_alltime.py: at HEAD the Mimura-Tsujikawa scripts run the chemotaxis
     operators on [0,16]^2 with 129 x 129 nodes and dt = 0.1 (chemotaxis_mimura_FCT.py:25-44, mimura_data_helpers.py:82-100;
-    delta = 2, Dm = Df = 0.05, chi = 0.125).  Forward synthetic at that grid, 20 steps, against the oracle."""
+    delta = 2, Dm = Df = 0.05, chi = 0.125).  Forward synthetic at that grid over the config's whole horizon, T = 30 =
+    300 steps (chemotaxis_mimura_FCT.py:39-44), against the oracle."""
     from oracle import traj as otraj
     systems = importlib.import_module("fem-fct-pdeco_amd.systems")
     monkeypatch.setattr(otraj, "chtxs_params", lambda: dict(delta=2, Dm=0.05, Df=0.05, chi=0.125, gamma=100, eta=0.5))
     omesh, asm = _oracle(0.0, 16.0, 128)
     V = hp.SquareMeshP1(0.0, 16.0, 128)
-    n, Nt, dt = V.nodes, 20, 0.1
+    n, Nt, dt = V.nodes, 300, 0.1
     assert n == 16641
     rng = np.random.default_rng(19)
     m0 = 1.0 + 0.05 * rng.random(n)
@@ -370,5 +457,5 @@ def test_mimura_named_grid_129x129_forward(hp, monkeypatch):
         eu, ev = rel(u.download(), uo), rel(v.download(), vo)
     finally:
         S.close()
-    _report("Mimura-named grid 129^2", u=eu, v=ev)
-    assert eu < TOL and ev < TOL and max(eu, ev) < EXPECT
+    _report("Mimura-named grid 129^2, 300 steps (T = 30)", u=eu, v=ev)
+    assert eu < TOL and ev < TOL

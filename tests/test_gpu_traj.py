@@ -208,31 +208,11 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
 
     # ---- oracle loop
     sb = otraj.SolidBody(asm, om=om)
-    M = sb.cm.M
     if optim == "alltime":      # target trajectory: the oracle's own forward solve at the true control c = 2
         uhat = np.zeros(tl); uhat[:n] = u0
         otraj.solidbody_forward(sb, 2.0 * np.ones(tl), uhat, n, Nt, dt)
-        uk = uhat.copy()
-    else:
-        uk = np.zeros(tl); uk[:n] = u0; uk[Nt * n:] = uhat
-    c_prev = c0.copy()
-    costs, ks = [], []
-    for it in range(iters):
-        pk = otraj.solidbody_adjoint(sb, c_prev, uk, uhat, np.zeros(tl), n, Nt, dt, optim=optim)
-        dk = otraj.solidbody_descent_direction(sb, c_prev, uk, pk, beta, n, Nt)
-        ck = np.clip(c_prev + s0 * dk, lo, hi)
-        otraj.solidbody_forward(sb, ck, uk, n, Nt, dt)
-        J_k = ofct.cost_functional(uk, uhat, ck, Nt, dt, M, beta, optim)
-        for k in range(max_armijo):
-            s = s0 * (1 / 2 ** k)
-            c_inc = np.clip(ck + s * dk, lo, hi)
-            otraj.solidbody_forward(sb, c_inc, uk, n, Nt, dt)
-            J = ofct.cost_functional(uk, uhat, c_inc, Nt, dt, M, beta, optim)
-            stat = ofct.l2_norm_sq_Q(c_inc - ck, Nt, dt, M)
-            if not (J - J_k > -gam / s * stat):
-                break
-        costs.append(J); ks.append(k + 1)
-        c_prev = c_inc
+    uk, _, c_prev, h_o = otraj.solidbody_pgd_loop(sb, u0, uhat, c0, beta, lo, hi, iters, n, Nt, dt, gam, s0, max_armijo, optim)
+    costs, ks = h_o["cost"], h_o["armijo_k"]
 
     prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1, 1, nc), Nt, dt, om=om)
     pgd = solvers.pgd_solidbody_finaltime if optim == "finaltime" else solvers.pgd_solidbody_alltime
@@ -240,6 +220,10 @@ def test_pgd_solidbody_matches_oracle_loop_and_speculative_equals_sequential(hp,
     u_q, p_q, c_q, h_q = pgd(prob, u0, uhat, c0, beta, lo, hi, iters, gam, s0, max_armijo, False)
     assert h_s["armijo_k"] == ks and h_q["armijo_k"] == ks
     assert np.allclose(h_s["cost"], costs, rtol=1e-9, atol=0)
+    # the accept / reject decisions are far from their thresholds (on both sides the same margins)
+    for ms_d, ms_o in zip(h_s["armijo_margin"], h_o["armijo_margin"]):
+        assert np.allclose(ms_d, ms_o, rtol=1e-6, atol=1e-9)
+    assert h_o["armijo_margin_min"] > 1e-7 and h_s["armijo_margin_min"] > 1e-7
     assert rel(c_s, c_prev) < 1e-8 and rel(u_s, uk) < 1e-8
     assert rel(c_s, c_q) < 1e-11 and rel(u_s, u_q) < 1e-11 and np.allclose(h_s["cost"], h_q["cost"], rtol=1e-11)
     prob.close()
