@@ -258,6 +258,8 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_T4_SNAKE")) ctx->t4_snake = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_PAIR")) ctx->t4_pair = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_PAIR_SHAPE")) ctx->pair_shape = atoi(e);
+    if (const char* e = getenv("FEMFCT_PAIR_PRIO")) ctx->pair_prio = atoi(e);
+    if (const char* e = getenv("FEMFCT_PAIR_SPLIT")) ctx->pair_split = std::min(90, std::max(10, atoi(e)));
     if (getenv("FEMFCT_PAIR_TRACE") && !ctx->d_pair_trace) {
         if (hipMalloc((void**)&ctx->d_pair_trace, sizeof(unsigned long long) * (FEMFCT_MAX_PARTIALS * 16 * 5 + 16)) == hipSuccess)
             hipMemset(ctx->d_pair_trace, 0, sizeof(unsigned long long) * (FEMFCT_MAX_PARTIALS * 16 * 5 + 16));

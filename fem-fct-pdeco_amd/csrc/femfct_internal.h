@@ -83,10 +83,11 @@ struct femfct_ctx {
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int t4_snake = 1;           // walking Jacobi launches alternate their direction (FEMFCT_T4_SNAKE)
-    bool t4_pair = false;       // upwind rows as one value per opposing pair: k_strip8_jacobi_pair_walk, two workgroups per CU (FEMFCT_T4_PAIR)
-    int pair_stagger = 500;     // FEMFCT_PAIR_STAGGER_US * 100: ticks of the 100 MHz clock the second half of the pair walkers waits
+    bool t4_pair = true;        // upwind rows as one value per opposing pair: k_strip8_jacobi_pair_walk, two workgroups per CU (FEMFCT_T4_PAIR)
+    int pair_stagger = 0;       // FEMFCT_PAIR_STAGGER_US * 100: ticks of the 100 MHz clock the second half of the pair walkers waits
     unsigned long long* d_pair_trace = nullptr;   // FEMFCT_PAIR_TRACE=<file>: phase timestamps of the pair walkers, dumped at destroy
-    int pair_shape = 0;         // FEMFCT_PAIR_SHAPE: 0 = 10 rows x 6 waves, 1 = 8 x 6, 2 = 16 x 4, 3 = 8 x 8 (measurement)
+    int pair_prio = 0, pair_split = 50;   // FEMFCT_PAIR_PRIO / FEMFCT_PAIR_SPLIT: balance between the two workgroups of a CU (k_strip_jacobi_pair_walk)
+    int pair_shape = 5;         // FEMFCT_PAIR_SHAPE: 0 = 10 rows x 6 waves, 1 = 8 x 6, 2 = 16 x 4, 3 = 8 x 8 (measurement)
     bool pair_rows = false;     // set by femfct_run_sweep for the sweep in progress: its kind has only shown upwind rows so far
     std::set<int> kind_fullrows;    // sweep kinds that raised FEMFCT_FLAG_ROW_PAIRS: full-row kernels from then on
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)

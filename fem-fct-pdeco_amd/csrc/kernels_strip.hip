@@ -1917,7 +1917,8 @@ __global__ void __launch_bounds__(64 * NST, (2 * NST + 3) / 4)
 k_strip_jacobi_pair_walk(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                          double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
                          int g_build, double rel_tol, int H, const uint8_t* __restrict__ lmask, int npy, int npatch,
-                         int up, int64_t zero_index, int stagger_ticks, unsigned long long* __restrict__ trace) {
+                         int up, int64_t zero_index, int stagger_ticks, unsigned long long* __restrict__ trace, int prio_mode,
+                         int first_half_pct) {
     constexpr int W = 7, PR = R * NST;
     __shared__ double top[2][NST][64], bot[2][NST][64];
     __shared__ double carry[PAIR_CARRY_ROWS][6][64];        // three pair values, diagonal, b, input iterate
@@ -1973,7 +1974,17 @@ k_strip_jacobi_pair_walk(int n, int N, const double* __restrict__ L_, const doub
     const unsigned un = (unsigned)n;
     const int st = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int T = T4_L - 2 * H, TY = PR - 2 * H;
-    const int q0 = (int)((int64_t)wg * npatch / nwg), q1 = (int)((int64_t)(wg + 1) * npatch / nwg);
+    // The two workgroups of a CU do not run at the same speed: issue arbitration prefers the older wave, so the workgroup
+    // dispatched second (the grid's second half) falls behind and ends up sweeping alone -- latency bound -- at the end.
+    // first_half_pct: share of the patches given to the first half of the walkers (50 = even); prio_mode 1: the two
+    // alternate in raised priority from patch to patch, 2: the younger one raised throughout.
+    int q0, q1;
+    {
+        const int half = nwg / 2;
+        const int np0 = (nwg >= 2 && first_half_pct != 50) ? (int)((int64_t)npatch * first_half_pct / 100) : (int)((int64_t)half * npatch / nwg);
+        if (wg < half) { q0 = (int)((int64_t)wg * np0 / half); q1 = (int)((int64_t)(wg + 1) * np0 / half); }
+        else { q0 = np0 + (int)((int64_t)(wg - half) * (npatch - np0) / (nwg - half)); q1 = np0 + (int)((int64_t)(wg - half + 1) * (npatch - np0) / (nwg - half)); }
+    }
     double rmax = 0.0;
     unsigned viol = 0;
     const int lx0 = threadIdx.x & 63;
@@ -2005,6 +2016,8 @@ k_strip_jacobi_pair_walk(int n, int N, const double* __restrict__ L_, const doub
         const int px = q / npy, py = q - px * npy;
         const bool cin = j > 0 && (up ? py + 1 < npy : py > 0);
         const bool cout = j + 1 < q1 - q0 && (up ? py > 0 : py + 1 < npy);
+        if (prio_mode == 1) { if ((j & 1) ^ (wg >= nwg / 2 ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        else if (prio_mode == 2 && j == 0 && wg >= nwg / 2) __builtin_amdgcn_s_setprio(1);
         // FEMFCT_PAIR_TRACE (tuning): 100 MHz timestamps of workgroup wg at patch start / rows in registers / after the
         // carry barrier / after the sweeps / after the stores were issued -- 5 words per patch, 16 patches per walker
         unsigned long long* tr = (trace && threadIdx.x == 0 && j < 16 && launch == 1) ? trace + ((int64_t)wg * 16 + j) * 5 : nullptr;
@@ -2718,7 +2731,7 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
 #define PAIR_LAUNCH(RR, NN)                                                                                              \
         hipLaunchKernelGGL((k_strip_jacobi_pair_walk<RR, NN>), dim3(walkers, 1, batch), dim3(64 * NN), 0, ctx->stream,    \
                            ctx->n, ctx->N, L, b, xa, xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, lmask, npy, \
-                           t * npy, ctx->t4_snake ? (launch & 1) : 0, (int64_t)ctx->ws_batch * ctx->W * ctx->n, ctx->pair_stagger, ctx->d_pair_trace)
+                           t * npy, ctx->t4_snake ? (launch & 1) : 0, (int64_t)ctx->ws_batch * ctx->W * ctx->n, ctx->pair_stagger, ctx->d_pair_trace, ctx->pair_prio, ctx->pair_split)
         switch (ctx->pair_shape) {
             case 1: PAIR_LAUNCH(8, 6); break;
             case 6: PAIR_LAUNCH(12, 4); break;
