@@ -108,6 +108,13 @@ def slotted_disc_ic(a1, a2, deltax, slit=0.05):
     return ((R < 1 / 3) & ((np.abs(X) > slit) | (Y > 0.5))).astype(np.float64).reshape(-1)
 
 
+def gaussian_ic(a1, a2, deltax):
+    """advection_solidbody_FCT_PDECO_alltime.py:62-74 (np.arange grid, vertex order)."""
+    X = np.arange(a1, a2 + deltax, deltax)
+    X, Y = np.meshgrid(X, X)
+    return np.exp(-20 * ((X + 2 / 3) ** 2 + 5 * (Y + 5 / 6) ** 2)).reshape(-1)
+
+
 def synthetic_control(x, y, v2d, num_steps):
     """Smooth space-time control in the admissible box [0,5] (synthetic data), FEniCS DoF order."""
     t = np.linspace(0.0, 1.0, num_steps + 1)[:, None]
@@ -241,10 +248,19 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo + fewer GPUs than ranks (ranks share GPUs round-robin) rehearses the whole "
                          "N > 1 run, real solver included, on a one-GPU box -- not a scaling measurement")
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 (default, the configuration BASELINE.json quotes the metric on): "
+                         "advection_solidbody_FCT_PDECO_finaltime, 250 + 250 steps, final-time misfit.  c5: the set-up of "
+                         "advection_solidbody_FCT_PDECO_alltime.py:43-74 (config 5's sweep member): 100 + 100 steps, no "
+                         "rotation, Gaussian initial condition, all-time misfit, target = own forward solve at c = 2")
+    ap.add_argument("--cpu-worker", type=str, default="", help=argparse.SUPPRESS)   # internal: one 1-core oracle process
     ap.add_argument("--stub-solver", action="store_true",
                     help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no library); not a measurement")
     args = ap.parse_args()
 
+    if args.cpu_worker:                      # child of cpu_baseline_sweep: CPU only, never touches the GPU or the library
+        print(json.dumps(cpu_worker(*args.cpu_worker.split(","))), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
@@ -261,10 +277,15 @@ def main():
 
     betas = [10.0 ** (-k / 2) for k in range(8)]          # C5 sweep values
     beta = betas[rank % len(betas)] if world > 1 else 1.0  # C2: beta = 1
-    a1, a2, deltax, dt, T = -1.0, 1.0, 0.1 / 2 / 2, 0.001, 0.25
+    c5 = args.workload == "c5"
+    a1, a2, deltax, dt, T = -1.0, 1.0, 0.1 / 2 / 2, 0.001, (0.1 if c5 else 0.25)
     n_cells = round((a2 - a1) / deltax)
     Nt = round(T / dt)
     om = np.pi / 40
+    rot_scale = 0.0 if c5 else 1.0           # alltime.py:146 multiplies Arot by 0
+    optim = "alltime" if c5 else "finaltime"
+    if c5 and world == 1:
+        beta = betas[3]                       # 10^-1.5, the value of tests/test_gpu_fullsize.py::test_c5_alltime_sweep_setup
     B = args.batch
 
     if args.stub_solver:
@@ -281,20 +302,31 @@ def main():
         tl = (Nt + 1) * n
         # device arrays live in dolfin vertex order (the library's fast layout: index-free stencil
         # addressing + 2-D tile kernels); the DoF-ordered arrays below feed the CPU oracle
-        prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, batch=B, device_id=device_id,
+        prob = solvers.SolidBodyDrift(mesh, Nt, dt, om=om, eps=0.0, rot_scale=rot_scale, batch=B, device_id=device_id,
                                       order=hp.ORDER_VERTEX)
         ctx = prob.ctx
         to_dev = lambda x: hp.reorder_vector_from_dof(x, x.size // n, n, mesh.vertex_to_dof)
         from_dev = lambda x: hp.reorder_vector_to_dof(x, x.size // n, n, mesh.vertex_to_dof)
-        u0 = hp.reorder_vector_to_dof(slotted_disc_ic(a1, a2, deltax), 1, n, mesh.vertex_to_dof)
         xs, ys = mesh.coordinates()
-        ck = synthetic_control(xs, ys, mesh.vertex_to_dof, Nt)
-        gpath = os.path.join(ROOT, "tests", "golden", "solidbody_t0.25_u.npz")
-        uhat = np.load(gpath)["u"] if os.path.exists(gpath) else np.roll(u0, 7)
+        if c5:
+            u0 = hp.reorder_vector_to_dof(gaussian_ic(a1, a2, deltax), 1, n, mesh.vertex_to_dof)
+            ck = np.ones(tl)                                             # c^0 = 1 (alltime.py:164)
+        else:
+            u0 = hp.reorder_vector_to_dof(slotted_disc_ic(a1, a2, deltax), 1, n, mesh.vertex_to_dof)
+            ck = synthetic_control(xs, ys, mesh.vertex_to_dof, Nt)
         init = np.zeros((B, tl))
         init[:, :n] = to_dev(u0)
         d_c = ctx.array(np.tile(to_dev(ck), B))
         d_u = ctx.array(init.reshape(-1))
+        if c5:      # target trajectory = the library's own forward solve at the true control c = 2 (alltime.py:93-123)
+            d_c2 = ctx.array(np.full(tl, 2.0))
+            d_t = ctx.array(init[0])
+            prob.forward(d_c2, d_t, batch=1)
+            uhat = from_dev(d_t.download())
+            d_c2.free(); d_t.free()
+        else:
+            gpath = os.path.join(ROOT, "tests", "golden", "solidbody_t0.25_u.npz")
+            uhat = np.load(gpath)["u"] if os.path.exists(gpath) else np.roll(u0, 7)
         d_p = ctx.zeros(B * tl)
         d_d = ctx.zeros(tl)
         d_rhs = ctx.empty(tl)
@@ -303,8 +335,8 @@ def main():
 
         def one_step():
             prob.forward(d_c, d_u, batch=B)
-            J = prob.cost(d_u, d_uhat, d_c, beta, "finaltime", batch=B)
-            prob.adjoint(d_c, d_u, d_uhat, d_p, "finaltime", batch=B)
+            J = prob.cost(d_u, d_uhat, d_c, beta, optim, batch=B)
+            prob.adjoint(d_c, d_u, d_uhat, d_p, optim, batch=B)
             prob.descent_direction(d_c, d_u, d_p, beta, d_d, scratch=d_rhs)   # batch member 0 (one control)
             return ranks.gather_costs(J[0])
 
@@ -323,8 +355,12 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "C2 advection_solidbody_FCT_PDECO_finaltime: [-1,1]^2 81x81 P1 (dx=0.025, n=6561), "
-                               "dt=1e-3, 250 fwd + 250 adj FCT steps per cost+gradient evaluation",
+        "config": {"workload": ("C5 advection_solidbody_FCT_PDECO_alltime set-up: [-1,1]^2 81x81 P1 (dx=0.025, n=6561), dt=1e-3, "
+                                "no rotation, Gaussian IC, all-time misfit, 100 fwd + 100 adj FCT steps per cost+gradient evaluation"
+                                if c5 else
+                                "C2 advection_solidbody_FCT_PDECO_finaltime: [-1,1]^2 81x81 P1 (dx=0.025, n=6561), "
+                                "dt=1e-3, 250 fwd + 250 adj FCT steps per cost+gradient evaluation"),
+                   "beta": beta,
                    "nodes": n, "num_steps": Nt, "dt": dt, "batch_per_gpu": B,
                    "parallelism": f"beta-sweep x{world}" if world > 1 else "single trajectory"},
         "cost": Js[0], "costs_all_ranks": Js if world > 1 else None,
@@ -340,6 +376,7 @@ def main():
     log = prob.solver_log(B)
     result["config"].update({"low_order_solver": "jacobi", "jacobi_sweeps_max": int(log["solver_iters"].max()),
                              "solver_resid_max": float(log["solver_resid"].max()), "graphs": True,
+                             "graph_replay": bool(ctx.graph_replay_active()),   # False under rocprofv3
                              "kernel_regime": int(ctx.kernel_regime(B)), "source_sha16": source_sha16()})
 
     # ---------------------------------------------------- per-kernel timing at C2 size
@@ -366,8 +403,8 @@ def main():
 
             def sweep():
                 prob.forward(cb, ub, batch=Bx)
-                prob.cost(ub, uhb, cb, beta, "finaltime", batch=Bx)
-                prob.adjoint(cb, ub, uhb, pb, "finaltime", batch=Bx)
+                prob.cost(ub, uhb, cb, beta, optim, batch=Bx)
+                prob.adjoint(cb, ub, uhb, pb, optim, batch=Bx)
 
             for _ in range(2):
                 sweep()
@@ -377,11 +414,33 @@ def main():
                 sweep()
             ctx.synchronize()
             el = (time.perf_counter() - t0) / 2
+            # which kernels a batch of Bx small trajectories runs: per-class launch time (HIP events) and the compulsory
+            # bytes of a launch over all Bx members / that time
+            regime_b = int(ctx.kernel_regime(Bx))
+            ctx.set_profiling(True)
+            prob.forward(cb, ub, batch=Bx)
+            repb = ctx.profile_report()
+            ctx.set_profiling(False)
+            infob = ctx.launch_info() if regime_b == 3 else None
+            bprb = launch_bytes_per_row(fused=regime_b >= 2 and repb["limit"][1] == 0, geom_mass=os.environ.get("FEMFCT_GEOM_MASS", "1") != "0",
+                                        inline_ops=repb["assemble"][1] == 0, half_d=regime_b == 3 and os.environ.get("FEMFCT_HALF_D", "1") != "0",
+                                        l_nonzero=ctx.lowop_nonzero_fraction() if regime_b == 3 else 1.0)
+            ktab = {}
+            for k, (ms, cnt) in repb.items():
+                if cnt:
+                    e = {"launches_per_step": cnt / Nt, "avg_launch_us": 1e3 * ms / cnt}
+                    if k in bprb and k != "assemble":
+                        e["compulsory_GBps"] = bprb[k] * n * Bx / (1e6 * ms / cnt)
+                        e["frac"] = e["compulsory_GBps"] / HBM_PEAK_GBS
+                    ktab[k] = e
             result["batched"].append({"batch_per_gpu": Bx, "value": 2 * Nt * Bx / el, "unit": "timesteps/s",
-                                      "ms_per_step": 1e3 * el})
+                                      "ms_per_step": 1e3 * el, "kernel_regime": regime_b,
+                                      "regime_name": {0: "one-sweep row kernels", 1: "row strips", 2: "32-patch tiles (latency regime)",
+                                                      3: "64-patch register strips (bandwidth regime)"}.get(regime_b, "?"),
+                                      "launch_info": infob, "kernels": ktab})
             for a in (cb, ub, pb, uhb):
                 a.free()
-    if rank == 0 and world == 1 and args.pgd_iters > 0:
+    if rank == 0 and world == 1 and args.pgd_iters > 0 and not c5:
         # the full optimisation loop of configs[1] (finaltime_Garvie.py:164-330), everything in HBM;
         # speculative = all 10 Armijo trial steps as one batch of independent trajectories
         pg = {}
@@ -391,19 +450,104 @@ def main():
                                                             args.pgd_iters, speculative=spec)
             dt_it = (time.perf_counter() - t0) / len(hist["cost"])
             pg["speculative" if spec else "sequential"] = {
-                "s_per_pgd_iteration": dt_it, "armijo_trials": hist["armijo_k"], "cost": hist["cost"][-1]}
+                "s_per_pgd_iteration": dt_it, "armijo_trials": hist["armijo_k"], "cost": hist["cost"][-1],
+                "armijo_margin_min": hist["armijo_margin_min"]}
         pg["cost_rel_diff"] = abs(pg["speculative"]["cost"] - pg["sequential"]["cost"]) / abs(pg["sequential"]["cost"])
+        pg["note"] = ("every line search exhausts on this data (slotted disc, reference target of another code version): the "
+                      "reference's behaviour, see DESIGN.md section 5; armijo_margin_min = smallest |J_trial - J_k + gam/s ||dc||^2| / |J_k| "
+                      "over the trials looked at")
         result["pgd_c2"] = pg
-    if rank == 0 and world == 1 and args.cpu_sample > 0:      # the CPU baseline is an N = 1 figure
+        # a loop whose decisions are mixed (config 5's set-up at beta = 1e-3: the first search exhausts, the next ones accept
+        # at the first trial; tests/test_gpu_fullsize.py compares it with the oracle loop)
+        from types import SimpleNamespace
+        Nt5 = 100
+        p5 = solvers.SolidBodyDrift(mesh, Nt5, dt, om=om, eps=0.0, rot_scale=0.0, batch=1, device_id=device_id, order=hp.ORDER_VERTEX)
+        try:
+            tl5 = (Nt5 + 1) * n
+            g0 = gaussian_ic(a1, a2, deltax)                       # vertex order = device order
+            c2 = p5.ctx.array(np.full(tl5, 2.0))
+            tgt = p5.ctx.array(np.concatenate([g0, np.zeros(tl5 - n)]))
+            p5.forward(c2, tgt, batch=1)
+            uhat5 = tgt.download()
+            c2.free(); tgt.free()
+            mix = {}
+            for spec in (True, False):
+                t0 = time.perf_counter()
+                _, _, _, h5 = solvers.pgd_solidbody_alltime(p5, g0, uhat5, np.ones(tl5), 1e-3, 0.0, 5.0, 3, max_armijo=6, speculative=spec)
+                mix["speculative" if spec else "sequential"] = {
+                    "s_per_pgd_iteration": (time.perf_counter() - t0) / len(h5["cost"]), "armijo_trials": h5["armijo_k"],
+                    "cost": h5["cost"][-1], "armijo_margin_min": h5["armijo_margin_min"]}
+            mix["same_decisions"] = mix["speculative"]["armijo_trials"] == mix["sequential"]["armijo_trials"]
+            mix["cost_rel_diff"] = abs(mix["speculative"]["cost"] - mix["sequential"]["cost"]) / abs(mix["sequential"]["cost"])
+            result["pgd_c5_mixed_decisions"] = mix
+        finally:
+            p5.close()
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
         # what the timed region left in HBM: batch member 0's state and adjoint trajectories for the control ck
         gpu_u = from_dev(d_u.download()[:tl])
         gpu_p = from_dev(d_p.download()[:tl])
-        base, par = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample, gpu_u, gpu_p)
+        base, par = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample, gpu_u, gpu_p,
+                                 rot_scale=rot_scale, optim=optim)
         result["cpu_baseline"] = base
         result["parity"] = par
-    ranks.close()
+    ranks.close()                 # (the ranks' collectives are over: what follows is rank 0's CPU-only leg)
+    if rank == 0 and world > 1 and args.cpu_sample > 0 and not args.stub_solver:
+        # the sweep's CPU baseline: N concurrent 1-core oracle processes, one per sweep
+        # member, on this node's host cores -- plain CPU children (they import NumPy / SciPy and oracle/ only)
+        result["cpu_baseline"] = cpu_baseline_sweep(world, args.workload, min(args.cpu_sample, Nt))
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def cpu_worker(workload, sample, beta_index):
+    """One member of the sweep's CPU baseline: forward + adjoint oracle sweep of `sample` steps on one thread."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    sample, beta_index = int(sample), int(beta_index)
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    from oracle import traj as otraj
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:  # pragma: no cover
+        pass
+    a1, a2, deltax, dt = -1.0, 1.0, 0.025, 1e-3
+    nc = round((a2 - a1) / deltax)
+    mesh = SquareMesh(a1, a2, nc)
+    asm = P1Assembler(mesh)
+    n = mesh.nodes
+    v2d = mesh.vertex_to_dof
+    c5 = workload == "c5"
+    u0 = np.zeros(n)
+    u0[v2d] = gaussian_ic(a1, a2, deltax) if c5 else slotted_disc_ic(a1, a2, deltax)
+    sb = otraj.SolidBody(asm, om=np.pi / 40, rot_scale=0.0 if c5 else 1.0)
+    tl = (sample + 1) * n
+    ck = np.ones(tl) if c5 else synthetic_control(mesh.x, mesh.y, v2d, sample)[:tl]
+    uhat = (0.9 * np.tile(u0, sample + 1)) if c5 else np.roll(u0, 7)
+    uk = np.zeros(tl)
+    uk[:n] = u0
+    t0 = time.perf_counter()
+    otraj.solidbody_forward(sb, ck, uk, n, sample, dt)
+    otraj.solidbody_adjoint(sb, ck, uk, uhat, np.zeros(tl), n, sample, dt, optim="alltime" if c5 else "finaltime")
+    return {"seconds": time.perf_counter() - t0, "steps": 2 * sample, "beta_index": beta_index}
+
+
+def cpu_baseline_sweep(n_proc, workload, sample):
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{workload},{sample},{k}"],
+                              stdout=subprocess.PIPE, text=True, env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES=""))
+             for k in range(n_proc)]
+    t0 = time.perf_counter()
+    outs = [p.communicate()[0] for p in procs]
+    wall = time.perf_counter() - t0
+    recs = [json.loads(o.strip().splitlines()[-1]) for o, p in zip(outs, procs) if p.returncode == 0 and o.strip()]
+    steps = sum(r["steps"] for r in recs)
+    slowest = max((r["seconds"] for r in recs), default=float("nan"))
+    return {"value": steps / slowest if recs else None, "unit": "timesteps/s", "cores": n_proc, "kind": "port",
+            "host_cpus": os.cpu_count(), "workers_ok": len(recs),
+            "sample": f"{n_proc} concurrent 1-thread oracle processes, each {sample} forward + {sample} adjoint FCT steps of the "
+                      f"{workload.upper()} workload (per-step assembly + vectorised NumPy/SciPy FCT step with SuperLU); "
+                      "value = all steps / the slowest worker's time",
+            "wall_s_incl_startup": wall}
 
 
 def _profiled_forward(prob, ctx, d_c, d_u, steps):
@@ -500,7 +644,8 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     dom_name = max(("jacobi", "cheb"), key=lambda k: kernels[k]["total_ms"])
     dom = kernels[dom_name]
     walkers = ctx.patch_walkers(1, sweeps // max(1, steps)) if regime == 3 else 0
-    sym = {3: {"jacobi": "k_strip4_jacobi_walk" if walkers else "k_strip4_jacobi<0>",
+    linfo = ctx.launch_info() if regime == 3 else {}
+    sym = {3: {"jacobi": {"k_strip_jacobi_pair_walk": "k_strip_jacobi_pair_walk<6, 8>"}.get(linfo.get("jacobi_kernel"), linfo.get("jacobi_kernel", "k_strip4_jacobi<0>")),
                "cheb": (("k_strip4_cheb_mass_int + k_strip4_cheb_mass on the boundary ring" if os.environ.get("FEMFCT_T4_INT", "1") != "0"
                          else "k_strip4_cheb_mass_walk") if walkers else "k_strip4_cheb_mass") if geom else "k_strip4_cheb"},
            2: {"jacobi": "k_tile_jacobi<H,0,BIG>", "cheb": "k_tile_cheb<H>"},
@@ -519,7 +664,8 @@ def roofline(hp, solvers, n_cells, steps, device_id):
                          "launch time by HIP events; frac = achieved / 8 TB/s",
            "workload": f"synthetic square mesh {n_cells + 1}x{n_cells + 1} (n={n}), vertex order, same CFL as C2",
            "compulsory_bytes_per_launch": dom["compulsory_bytes_per_row_per_launch"] * n,
-           "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "patch_walkers": walkers, "source_sha16": sha,
+           "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "patch_walkers": linfo.get("jacobi_walkers", walkers),
+           "launch_info": linfo, "source_sha16": sha,
            "operator": "derived inside k_build_low_sb / k_dudt_rhs_sb" if inline_ops else "stored by k_ops_solidbody",
            "low_order_offdiag_nonzero_fraction": l_nonzero, "d_stored_once_per_edge": half_d,
            "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms, "jacobi_sweeps_per_step": sweeps / steps,
@@ -554,7 +700,7 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     return out
 
 
-def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, gpu_p=None):
+def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, gpu_p=None, rot_scale=1.0, optim="finaltime"):
     """CPU oracle (test infrastructure) timed on this host as the reported CPU baseline, and -- the oracle being
     the checker -- compared with the GPU trajectories the timed region produced for the same inputs."""
     from oracle.mesh import SquareMesh
@@ -568,7 +714,7 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, 
     mesh = SquareMesh(a1, a2, n_cells)
     asm = P1Assembler(mesh)
     n = mesh.nodes
-    sb = otraj.SolidBody(asm, om=om)
+    sb = otraj.SolidBody(asm, om=om, rot_scale=rot_scale)
     ns = min(sample, Nt)
     uk = np.zeros((ns + 1) * n)
     uk[:n] = u0
@@ -576,7 +722,7 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, 
     t0 = time.perf_counter()
     otraj.solidbody_forward(sb, c, uk, n, ns, dt)
     pk = np.zeros_like(uk)
-    otraj.solidbody_adjoint(sb, c, uk, uhat, pk, n, ns, dt, optim="finaltime")
+    otraj.solidbody_adjoint(sb, c, uk, uhat[:(ns + 1) * n] if optim == "alltime" else uhat, pk, n, ns, dt, optim=optim)
     t_vec = time.perf_counter() - t0
     rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     parity = None
@@ -585,7 +731,7 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, 
         parity = {"u_rel_l2": rel(gpu_u[:m], uk), "u_final_rel_l2": rel(gpu_u[ns * n:m], uk[ns * n:]),
                   "p_rel_l2": rel(gpu_p[:m], pk) if ns == Nt else None, "tol": 1e-6,
                   "levels_compared": ns + 1,
-                  "what": "GPU state/adjoint trajectories of the timed C2 run vs the CPU oracle on the same control, "
+                  "what": "GPU state/adjoint trajectories of the timed run vs the CPU oracle on the same control, "
                           "initial condition and target (81x81, dt 1e-3)"}
         parity["ok"] = bool(parity["u_rel_l2"] < 1e-6 and (parity["p_rel_l2"] is None or parity["p_rel_l2"] < 1e-6))
     # reference-cost-profile variant (LIL + interpreter loops, the reference's data structures)
@@ -599,7 +745,7 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, 
     if limiter is not None and hasattr(limiter, "unregister"):
         limiter.unregister()
     base = {"value": 2 * ns / t_vec, "unit": "timesteps/s", "cores": 1, "kind": "port",
-            "sample": f"{ns} forward + {ns} adjoint FCT steps of the C2 workload (per-step assembly + "
+            "sample": f"{ns} forward + {ns} adjoint FCT steps of the {'C5' if optim == 'alltime' else 'C2'} workload (per-step assembly + "
                       f"vectorised NumPy/SciPy FCT step with SuperLU), 1 thread",
             "host_cpus": os.cpu_count(),
             "reference_profile_variant": {"value": 1.0 / t_lil, "unit": "timesteps/s",

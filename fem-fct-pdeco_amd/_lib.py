@@ -72,6 +72,7 @@ SIGNATURES = {
     "femfct_set_solver": (C.c_int, [_p, C.c_int, _d, C.c_int]),
     "femfct_set_graphs": (C.c_int, [_p, C.c_int]),
     "femfct_graph_replay_active": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "femfct_launch_info": (C.c_int, [_p, C.POINTER(C.c_int32)]),
     "femfct_set_fusion": (C.c_int, [_p, C.c_int, C.c_int]),
     "femfct_kernel_regime": (C.c_int, [_p, _i]),
     "femfct_patch_walkers": (C.c_int, [_p, _i, _i]),

@@ -432,6 +432,15 @@ int femfct_patch_walkers(const femfct_ctx* ctx, int32_t batch, int32_t sweeps) {
     return femfct_tile4_walkers(ctx, femfct_tile4_halo(ctx, sweeps > 0 ? sweeps : 36), batch, false);
 }
 
+// Which bandwidth-regime kernels the most recent step / sweep enqueued: out[0] Jacobi launch (0 none or another regime,
+// 1 one workgroup per patch, 2 k_strip4_jacobi_walk, 3 k_strip_jacobi_pair_walk), out[1] its walkers, out[2] interior
+// patches per side of the split Chebyshev launch (0: not split), out[3] halo depth of the Jacobi launch.  Diagnostic.
+int femfct_launch_info(const femfct_ctx* ctx, int32_t* out4_host) {
+    if (!ctx || !out4_host) return FEMFCT_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) out4_host[k] = ctx->last_launch[k];
+    return FEMFCT_OK;
+}
+
 // Share of the off-diagonal entries of the most recent low-order operator (batch member 0) that are non-zero, i.e.
 // that the 64-patch Jacobi launches actually load; 1.0 when the zero mask is not in use.  Diagnostic for bench.py:
 // the compulsory bytes of a launch "as executed" must not count entries the kernel never touches.  Synchronises.

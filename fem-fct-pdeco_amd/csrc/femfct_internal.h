@@ -85,6 +85,9 @@ struct femfct_ctx {
     int t4_snake = 1;           // walking Jacobi launches alternate their direction (FEMFCT_T4_SNAKE)
     bool t4_pair = true;        // upwind rows as one value per opposing pair: k_strip8_jacobi_pair_walk, two workgroups per CU (FEMFCT_T4_PAIR)
     int pair_stagger = 0;       // FEMFCT_PAIR_STAGGER_US * 100: ticks of the 100 MHz clock the second half of the pair walkers waits
+    // what the most recent bandwidth-regime launches were (femfct_launch_info): Jacobi kernel (0 none, 1 one workgroup per
+    // patch, 2 k_strip4_jacobi_walk, 3 k_strip_jacobi_pair_walk), its walkers, interior Chebyshev patches per side, halo depth
+    int32_t last_launch[4] = {0, 0, 0, 0};
     unsigned long long* d_pair_trace = nullptr;   // FEMFCT_PAIR_TRACE=<file>: phase timestamps of the pair walkers, dumped at destroy
     int pair_prio = 0, pair_split = 50;   // FEMFCT_PAIR_PRIO / FEMFCT_PAIR_SPLIT: balance between the two workgroups of a CU (k_strip_jacobi_pair_walk)
     int pair_shape = 5;         // FEMFCT_PAIR_SHAPE: 0 = 10 rows x 6 waves, 1 = 8 x 6, 2 = 16 x 4, 3 = 8 x 8 (measurement)

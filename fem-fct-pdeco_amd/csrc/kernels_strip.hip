@@ -2726,6 +2726,9 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
     femfct_prof_begin(ctx, KC_JACOBI);
     const bool pair = check_every <= 0 && femfct_jacobi_pair_wanted(ctx, H, batch, lmask != nullptr);
     const int walkers = check_every > 0 ? 0 : femfct_tile4_walkers(ctx, H, batch, pair);
+    ctx->last_launch[0] = pair ? 3 : walkers > 0 ? 2 : ctx->t4_dpp ? 1 : 0;
+    ctx->last_launch[1] = walkers;
+    ctx->last_launch[3] = H;
     if (pair) {
         const int npy = pair_tiles_y(ctx, H);
 #define PAIR_LAUNCH(RR, NN)                                                                                              \
@@ -2802,6 +2805,7 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
         if (io_in && k0 == k_first) { io.mid_ref = io_in->mid_ref; io.mid_bs = io_in->mid_bs; }
         if (io_in && last) { io.out_ref = io_in->out_ref; io.out_bs = io_in->out_bs; }
         femfct_prof_begin(ctx, KC_CHEB);
+        ctx->last_launch[2] = (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && n_int > 0 && (int64_t)t * t * batch > ctx->num_cus) ? n_int : 0;
         if (ctx->t4_dpp && femfct_geom_mass(ctx) && !io_in && n_int > 0 && (int64_t)t * t * batch > ctx->num_cus) {
             // more patches than compute units: the interior ones two workgroups to a CU, the boundary ring by the general kernel
             hipLaunchKernelGGL(k_strip4_cheb_mass_int, dim3(n_int, n_int, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N,

@@ -125,6 +125,15 @@ class Context:
     def set_graphs(self, enable: bool):
         check(self.handle, lib.femfct_set_graphs(self.handle, int(bool(enable))))
 
+    def launch_info(self) -> dict:
+        """Bandwidth-regime kernels of the most recent step / sweep (diagnostic): Jacobi launch kind, its walkers, interior
+        patches per side of the split Chebyshev launch, halo depth."""
+        out = (C.c_int32 * 4)()
+        check(self.handle, lib.femfct_launch_info(self.handle, out))
+        kinds = {0: "other", 1: "k_strip4_jacobi", 2: "k_strip4_jacobi_walk", 3: "k_strip_jacobi_pair_walk"}
+        return {"jacobi_kernel": kinds.get(out[0], "?"), "jacobi_walkers": int(out[1]), "cheb_interior_patches": int(out[2]),
+                "halo": int(out[3])}
+
     def graph_replay_active(self) -> bool:
         """False while sweeps are enqueued kernel by kernel: graphs off, per-class profiling, or rocprofv3 attached."""
         v = C.c_int(0)

@@ -69,7 +69,8 @@ class SystemPDECO:
             from .systems import _wind_factors
             self.par, wind0 = _schnak_par()
             self.Aw, self.AwT = self.S.convection(wind or wind0, None if wind is not None else "schnak")
-            self.wscale = _wind_factors(wind_scale, self.Nt, self.dt)
+            self.wscale = _wind_factors(wind_scale, self.Nt, self.dt)                               # forward: t += dt
+            self.wscale_adj = _wind_factors(wind_scale, self.Nt, self.dt, T=self.Nt * self.dt)      # adjoint: t = T; t -= dt
         else:
             self.par = _chtxs_par()
         self._arrays = []
@@ -130,7 +131,7 @@ class SystemPDECO:
             self.ctx.nonlinear_adjoint(self.Aw, u, tg[0], p, self.Nt, self.dt, self.eps)
         elif self.problem == "schnak":
             self.ctx.schnak_adjoint(self.AwT, u, v, tg[0], tg[1], p, q, self.Nt, self.dt, self.par,
-                                    alltime=self.P["optim"] == "alltime", wind_scale=self.wscale)
+                                    alltime=self.P["optim"] == "alltime", wind_scale=self.wscale_adj)
         else:
             self.ctx.chtxs_adjoint(u, v, tg[0], tg[1], p, q, c, self.Nt, self.dt, self.par, self.P["rescaling"],
                                    self.P["optim"] == "alltime")

@@ -90,6 +90,10 @@ int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay o
  * rocprofiler-sdk tool (rocprofv3) is attached to the process: its HSA queue interceptor in ROCm 7.2.0 reads a graph
  * launch's packet batch past the end of the queue ring (host SIGSEGV); FEMFCT_PROFILER_GRAPHS=1 overrides.  No reference
  * counterpart (diagnostic). */
+/* Which bandwidth-regime kernels the most recent step / sweep enqueued: out[0] Jacobi launch (0 none or another regime,
+ * 1 one workgroup per patch, 2 k_strip4_jacobi_walk, 3 k_strip_jacobi_pair_walk), out[1] its walkers, out[2] interior patches
+ * per side of the split Chebyshev launch (0: not split), out[3] halo depth.  No reference counterpart (diagnostic). */
+int         femfct_launch_info(const femfct_ctx* ctx, int32_t* out4_host);
 int         femfct_graph_replay_active(const femfct_ctx* ctx, int* active_host);
 /* multi-sweep fusion of the Jacobi / Chebyshev kernels: row strips (any banded pattern) and 2-D tiles
  * (structured mesh in vertex order); both default on, results agree with the one-sweep kernels to the

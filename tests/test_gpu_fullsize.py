@@ -325,6 +325,54 @@ def test_bandwidth_regime_kernels_vs_oracle(hp, solvers, nc, walkers, monkeypatc
         prob.close()
 
 
+def test_bandwidth_regime_self_selected_kernels_1025x1025_vs_oracle(hp, solvers, monkeypatch):
+    """The kernels a large mesh picks BY ITSELF -- no FEMFCT_T4_WALKERS override: at 1025^2 nodes (23 x 23 patches on 256
+    compute units) the walking Jacobi launch (pair-compact variant, two workgroups per CU, where the operator's rows allow
+    it) and the split Chebyshev launch (interior patches by the 64-VGPR kernel + boundary ring) -- against the CPU oracle:
+    1 forward + 1 adjoint step of 1.05 M nodes (helpers.py:1715-1872; finaltime.py:175-221)."""
+    from oracle import traj as otraj
+    monkeypatch.delenv("FEMFCT_T4_WALKERS", raising=False)
+    nc, Nt = 1024, 1
+    omesh, asm = _oracle(-1.0, 1.0, nc)
+    n = omesh.nodes
+    dt = 1e-3 * (2.0 / nc) / 0.025
+    rng = np.random.default_rng(23)
+    x, y = omesh.x, omesh.y
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1)
+    v2d = omesh.vertex_to_dof
+
+    def to_dof(a):
+        out = np.empty_like(a.reshape(-1, n))
+        out[:, v2d] = a.reshape(-1, n)
+        return out.reshape(-1)
+
+    sb = otraj.SolidBody(asm, om=np.pi / 40)
+    uk_o = np.zeros((Nt + 1) * n)
+    uk_o[:n] = to_dof(u0)
+    otraj.solidbody_forward(sb, to_dof(c), uk_o, n, Nt, dt)
+    uhat_o = 0.9 * uk_o[Nt * n:] + 0.01
+    pk_o = otraj.solidbody_adjoint(sb, to_dof(c), uk_o, uhat_o, np.zeros_like(uk_o), n, Nt, dt, optim="finaltime")
+    prob = solvers.SolidBodyDrift(hp.SquareMeshP1(-1.0, 1.0, nc), Nt, dt, order=hp.ORDER_VERTEX)
+    try:
+        uk = np.zeros((Nt + 1) * n)
+        uk[:n] = u0
+        prob.solve_state(c, uk)
+        assert not np.any(prob.solver_log(1)["flags"] & hp.FLAG_SOLVER_BUDGET)
+        info = prob.ctx.launch_info()
+        if _fusion_knobs_on() and all(os.environ.get(k, "1") == "1" for k in ("FEMFCT_T4_WALK", "FEMFCT_T4_INT", "FEMFCT_LMASK", "FEMFCT_T4_PAIR")):
+            assert prob.ctx.uses_bandwidth_tiles(1)
+            assert prob.ctx.patch_walkers(1) == 256, prob.ctx.patch_walkers(1)       # MI355X: one 1024-thread walker per CU
+            assert info["jacobi_kernel"] == "k_strip_jacobi_pair_walk" and info["jacobi_walkers"] > 256, info
+            assert info["cheb_interior_patches"] > 0, info                            # the interior Chebyshev launch was taken
+        pk = prob.solve_adjoint(c, uk, uhat_o.reshape(-1, n)[:, v2d].reshape(-1), np.zeros_like(uk), optim="finaltime")
+        eu, ep = rel(to_dof(uk), uk_o), rel(to_dof(pk), pk_o)
+        _report(f"self-selected bandwidth kernels 1025^2 ({info})", u_rel_l2=eu, p_rel_l2=ep)
+        assert eu < 1e-9 and ep < 1e-9
+    finally:
+        prob.close()
+
+
 def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch):
     """Four shortcuts of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
     operator derived inside k_build_low_sb / k_dudt_rhs_sb instead of stored by k_ops_solidbody and read back;

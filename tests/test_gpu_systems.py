@@ -2,6 +2,7 @@
 (-m gpu): the drop-in ``solve_*`` functions against the CPU oracle and, for the chemotaxis forward
 problem, directly against the real-FEniCS trajectory shipped by the reference."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -362,3 +363,34 @@ def test_schnak_time_dependent_wind_of_the_named_config3_script(hp):
     assert np.array_equal(u1, us) and np.array_equal(v1, vs)
     with pytest.raises(ValueError):
         hp.solve_schnak_system(ctrl, z(u0), z(v0), V, n, Nt, dt, None, wind=rot, wind_scale=np.ones(Nt))
+
+
+def test_unnamed_wind_cache_is_bounded(hp):
+    """PDESystems.convection keys a bare wind function on the function object; a caller that builds a new lambda per call
+    must not grow the device-side cache without bound."""
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    S = systems.PDESystems(hp.SquareMeshP1(0.0, 1.0, 8))
+    try:
+        first = None
+        for k in range(3 * S.MAX_UNNAMED_WINDS):
+            A, AT = S.convection(lambda x, y, k=k: ((y - 0.5) * (1 + k), -(x - 0.5)))
+            first = first or (A, AT)
+        assert sum(1 for key in S._conv if callable(key)) <= S.MAX_UNNAMED_WINDS
+        assert first[0].ptr == 0 and first[1].ptr == 0          # the oldest pair was freed
+        named = S.convection(lambda x, y: (x, y), "mine")
+        assert S.convection(lambda x, y: (y, x), "mine") is named       # named winds are kept and reused
+    finally:
+        S.close()
+
+
+def test_graph_replay_is_active_outside_a_profiler(hp):
+    ctx = hp.Context(0)
+    try:
+        if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+            assert not ctx.graph_replay_active()
+        else:
+            assert ctx.graph_replay_active()
+        ctx.set_graphs(False)
+        assert not ctx.graph_replay_active()
+    finally:
+        ctx.close()

@@ -146,3 +146,26 @@ def test_sparse_nonzero_matches_reference():
     assert nz.shape == ref.shape == (K.nnz, 4)
     assert np.array_equal(nz, ref)
     assert set(np.unique(nz[:, 3])) <= {0.0, 1.0} and np.array_equal(nz[:, 3] == 1.0, nz[:, 2] > 0)
+
+
+def test_wind_factor_time_levels_accumulate_like_the_reference_loops():
+    """helpers.py:565-566 (``t += dt`` forward) and :664, 679 (``t = T; t -= dt`` adjoint): the wind factors handed to the
+    device are evaluated at the reference's accumulated time levels, not at t0 + k*dt."""
+    import importlib
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    Nt, dt, T = 200, 1e-3, 0.2
+    s = lambda t: np.sin(2 * np.pi * t)
+    fwd = systems._wind_factors(s, Nt, dt)
+    t, ref = 0.0, [s(0.0)]
+    for _ in range(Nt):
+        t += dt
+        ref.append(s(t))
+    assert np.array_equal(fwd, np.array(ref))
+    adj = systems._wind_factors(s, Nt, dt, T=T)
+    t, ref = T, {Nt: s(T)}
+    for i in reversed(range(Nt)):
+        t -= dt
+        ref[i] = s(t)
+    assert np.array_equal(adj, np.array([ref[k] for k in range(Nt + 1)]))
+    assert not np.array_equal(fwd, np.array([s(k * dt) for k in range(Nt + 1)]))     # the shortcut differs in the last bits
+    assert systems._wind_factors(None, Nt, dt) is None

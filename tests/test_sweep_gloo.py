@@ -110,3 +110,18 @@ def test_bench_refuses_mismatched_world_size():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-solver"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_sweep_cpu_baseline_runs_concurrent_one_core_workers():
+    """bench.py --gpus N > 1 reports the sweep's CPU baseline as N concurrent 1-core oracle processes (SURVEY 8d,
+    BASELINE.md 4.2): here 2 workers x (3 + 3) steps of config 5's set-up, plain CPU children."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline_sweep(2, "c5", 3)
+    assert out["cores"] == 2 and out["workers_ok"] == 2 and out["kind"] == "port"
+    assert out["value"] > 0 and out["unit"] == "timesteps/s"
+    one = bench.cpu_worker("c2", "2", "0")
+    assert one["steps"] == 4 and one["seconds"] > 0

@@ -19,7 +19,7 @@ import sys
 
 # kernel -> class, separately for the product path at the roofline size (fused multi-sweep kernels, operator derived
 # in the kernels) and for the fusions-off pass of bench.py (one-sweep kernels); both run in the same bench.py process
-PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_strip4_jacobi_walk": "jacobi", "k_strip4_cheb_mass_walk": "cheb",
+PRODUCT = {"k_build_low_sb": "build_low", "k_strip4_jacobi": "jacobi", "k_strip4_jacobi_walk": "jacobi", "k_strip_jacobi_pair_walk": "jacobi", "k_strip4_cheb_mass_walk": "cheb",
            "k_strip4_cheb_mass_int": "cheb", "k_dudt_rhs_sb": "dudt_rhs", "k_strip4_cheb_mass": "cheb",
            "k_strip4_cheb": "cheb", "k_tile_flux_limit": "flux", "k_tile_jacobi": "jacobi", "k_tile_cheb": "cheb",
            "k_tile4_jacobi": "jacobi", "k_tile4_cheb": "cheb"}
