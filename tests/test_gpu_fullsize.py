@@ -357,10 +357,15 @@ def test_bandwidth_regime_self_selected_kernels_1025x1025_vs_oracle(hp, solvers,
     try:
         uk = np.zeros((Nt + 1) * n)
         uk[:n] = u0
-        prob.solve_state(c, uk)
+        prob.solve_state(c, uk)              # first sweep of a context: 48 sweeps budgeted = 6 x 8, halo 8, 22 x 22 patches
+        assert not np.any(prob.solver_log(1)["flags"] & hp.FLAG_SOLVER_BUDGET)
+        first = prob.ctx.launch_info()
+        uk[n:] = 0.0
+        prob.solve_state(c, uk)              # budget settled at what the operator needs (36 = 4 x 9): halo 9, 23 x 23 patches
         assert not np.any(prob.solver_log(1)["flags"] & hp.FLAG_SOLVER_BUDGET)
         info = prob.ctx.launch_info()
         if _fusion_knobs_on() and all(os.environ.get(k, "1") == "1" for k in ("FEMFCT_T4_WALK", "FEMFCT_T4_INT", "FEMFCT_LMASK", "FEMFCT_T4_PAIR")):
+            assert first["jacobi_kernel"] == "k_strip4_jacobi" and first["cheb_interior_patches"] > 0, first
             assert prob.ctx.uses_bandwidth_tiles(1)
             assert prob.ctx.patch_walkers(1) == 256, prob.ctx.patch_walkers(1)       # MI355X: one 1024-thread walker per CU
             assert info["jacobi_kernel"] == "k_strip_jacobi_pair_walk" and info["jacobi_walkers"] > 256, info

@@ -1,13 +1,13 @@
 #!/bin/bash
 # One pass on ONE MI355X box that regenerates everything under profiles/ from the library as built from the
 # current sources, so that kernel stats, PMC traffic and the bench line describe the same binary:
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 1190 -- 'bash tools/refresh_profiles.sh r03'
 # Outputs land in gpurun_out/prof/ (merged back by gpurun); copy them into profiles/ with
-#   cp gpurun_out/prof/r02_* gpurun_out/prof/traffic.json profiles/
+#   cp gpurun_out/prof/r03_* gpurun_out/prof/traffic.json profiles/
 # Order: PMC passes first (traffic.json, stamped with source_sha16), then the plain bench run (whose
 # roofline.traffic echoes that stamp-checked file), then the kernel trace.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
@@ -30,5 +30,11 @@ echo "[refresh] kernel trace"
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --cpu-sample 0 --batched= > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-rm -rf $OUT/kt $OUT/pf $OUT/pw $OUT/fetch.csv $OUT/write.csv
+echo "[refresh] kernel trace of the BATCHED regime (64 C2 trajectories per launch: the lever at the config sizes)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kb -- python3 $REPO/bench.py --batch 64 --steps 3 --warmup 1 --roofline-cells 0 --cpu-sample 0 --pgd-iters 0 --batched= > $OUT/${TAG}_bench_batch64_under_rocprof.json 2> $OUT/kb.err
+cp $(find $OUT/kb -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_batch64_kernel_stats.csv
+echo "[refresh] the other systems' sweeps under the same profiler command that used to fault (DESIGN.md section 9)"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -- python3 $REPO/tools/bench_systems.py > $OUT/${TAG}_systems_under_rocprof.txt 2>&1 && echo "exit code 0" >> $OUT/${TAG}_systems_under_rocprof.txt || echo "exit code $? (non-zero)" >> $OUT/${TAG}_systems_under_rocprof.txt
+cp $(find $OUT/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_systems_kernel_stats.csv 2>/dev/null || true
+rm -rf $OUT/kt $OUT/kb $OUT/ks $OUT/pf $OUT/pw $OUT/fetch.csv $OUT/write.csv
 ls -la $OUT
