@@ -55,4 +55,6 @@ def test_bench_two_ranks_real_solver_on_one_gpu_gloo():
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["parallelism"] == "beta-sweep x2"
     J = r["costs_all_ranks"]
     assert len(J) == 2 and J[0] > 0 and J[1] > 0 and J[0] != J[1]            # beta = 1 and 10^-1/2: different costs
-    assert "cpu_baseline" not in r and "batched" not in r                    # N = 1 legs only
+    assert "batched" not in r and "parity" not in r                          # N = 1 legs only
+    cb = r["cpu_baseline"]                                                   # the sweep's: N concurrent 1-core oracle processes
+    assert cb["cores"] == 2 and cb["workers_ok"] == 2 and cb["kind"] == "port" and cb["value"] > 0

@@ -17,13 +17,17 @@ C=("FEMFCT_T4_INT=0" "FEMFCT_T4_SNAKE=0" "FEMFCT_T4_STAGGER_US=0" "FEMFCT_SPECIE
 case $PART in a) SET=("${A[@]}");; b) SET=("${B[@]}");; c) SET=("${C[@]}");; *) SET=("${A[@]}" "${B[@]}" "${C[@]}");; esac
 : > $F
 if [ "$PART" = a ] || [ "$PART" = all ]; then
-  r=$(timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -1)
+  o=$(timeout -k 10 900 python -m pytest tests -m gpu -q -rf 2>&1)
+  r=$(echo "$o" | tail -1)
   echo "(default setting, whole suite)          : $r" >> $F
+  echo "$o" | grep "^FAILED" | sed 's/^/    /' >> $F
   echo "[knobs] default: $r"
 fi
 for kv in "${SET[@]}"; do
-  r=$(env $kv timeout -k 10 600 python -m pytest tests -m gpu -q -k "$SKIP" 2>&1 | tail -1)
+  o=$(env $kv timeout -k 10 600 python -m pytest tests -m gpu -q -rf -k "$SKIP" 2>&1)
+  r=$(echo "$o" | tail -1)
   printf "%-40s: %s\n" "$kv" "$r" >> $F
+  echo "$o" | grep "^FAILED" | sed 's/^/    /' >> $F
   echo "[knobs] $kv: $r"
 done
 echo "source_sha16 $(python -c 'import bench; print(bench.source_sha16())'); heavy oracle tests deselected for the non-default settings: -k \"$SKIP\"" >> $F
