@@ -418,6 +418,51 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
             assert np.array_equal(uk, outs[0][0]) and np.array_equal(pk, outs[0][1])
 
 
+@pytest.mark.parametrize("control", ["smooth", "rough", "diffusive"])
+def test_pair_compact_jacobi_launch_is_bitwise_the_full_row_launch(hp, solvers, monkeypatch, control):
+    """k_strip_jacobi_pair_walk (one value per opposing stencil pair, two workgroups per CU) against the full-row walking
+    launch it replaces: same bits, forward + all-time adjoint at 331^2 nodes with the walks forced onto the small mesh.
+    smooth control: ~0.1 % of the rows hold both entries of a pair (pool records); rough (random) control: ~2 % do;
+    diffusive (eps > 0): every row does -- the pool overflows, the kernel raises FEMFCT_FLAG_ROW_PAIRS and the sweep is
+    repeated with the full-row kernels (so the answer is theirs by construction, and no flag reaches the caller)."""
+    nc, Nt = 330, 2
+    mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
+    n = mesh.nodes
+    dt = 1e-3 * (2.0 / nc) / 0.025
+    x, y = mesh.coordinates()
+    rng = np.random.default_rng(41)
+    u0 = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+    c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1)
+    if control == "rough":
+        c = 2.0 * rng.random((Nt + 1) * n)
+    eps = 1e-3 if control == "diffusive" else 0.0
+    monkeypatch.setenv("FEMFCT_T4_WALKERS", "9")
+    outs, kernels = [], []
+    for pair in ("1", "0"):
+        monkeypatch.setenv("FEMFCT_T4_PAIR", pair)
+        prob = solvers.SolidBodyDrift(mesh, Nt, dt, eps=eps, order=hp.ORDER_VERTEX)
+        try:
+            uk = np.zeros((Nt + 1) * n)
+            uk[:n] = u0
+            prob.solve_state(c, uk)
+            kernels.append(prob.ctx.launch_info()["jacobi_kernel"])
+            flags = prob.solver_log(1)["flags"]
+            assert not np.any(flags & hp.FLAG_SOLVER_BUDGET) and not np.any(flags & 16)       # 16: FEMFCT_FLAG_ROW_PAIRS (internal)
+            pk = prob.solve_adjoint(c, uk, 0.9 * uk + 0.01, np.zeros_like(uk), optim="alltime")
+            outs.append((uk.copy(), pk.copy()))
+        finally:
+            prob.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    if _fusion_knobs_on() and all(os.environ.get(k, "1") == "1" for k in ("FEMFCT_T4_WALK", "FEMFCT_LMASK", "FEMFCT_T4_DPP")) \
+            and os.environ.get("FEMFCT_T4_K", "8") == "8":
+        assert kernels[1] == "k_strip4_jacobi_walk"
+        if control == "smooth":
+            assert kernels[0] == "k_strip_jacobi_pair_walk", kernels
+        elif control == "diffusive":
+            assert kernels[0] == "k_strip4_jacobi_walk", kernels          # fell back for this kind of sweep
+        print(f"[fullsize] pair-compact launch, {control} control: kernel {kernels[0]}")
+
+
 def test_c5_alltime_sweep_setup_81x81_100_steps(hp, solvers):
     """BASELINE configs[4] (advection_solidbody_FCT_PDECO_alltime.py:43-74,93-123,146,164): [-1,1]^2 81 x 81, dt 1e-3,
     T = 0.1, rotation switched off (Arot * 0), Gaussian initial condition, all-time misfit -- forward at the true control

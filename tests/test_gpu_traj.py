@@ -326,8 +326,12 @@ def test_deferred_residual_test_reproduces_the_in_launch_one(hp, solvers, monkey
         assert np.array_equal(u0_, u1_) and np.array_equal(p0_, p1_)
         for a, b in ((lf0, lf1), (la0, la1)):
             # two to four launches, all needed: the case the deferral covers (dt = 1e-3: 3 x 12 or 4 x 10 sweeps)
-            if tile_regime:
-                assert 13 * (launches - 1) < int(a["solver_iters"].max()) <= 13 * (launches + (launches > 2)), a["solver_iters"].max()
+            worst = int(a["solver_iters"].max())
+            # whatever kernels a knob selects, the operator needs 24-26 (dt = 4e-4) / 33-36 (dt = 1e-3) Jacobi sweeps; fused
+            # launches report whole launches of 8-13 sweeps on top of that
+            assert (18, 30)[launches > 2] <= worst <= (30, 52)[launches > 2], worst
+            if tile_regime and os.environ.get("FEMFCT_DEEP_HALO", "1") != "0":
+                assert 13 * (launches - 1) < worst <= 13 * (launches + (launches > 2)), worst
             for k in a:
                 assert np.array_equal(a[k], b[k]), k
 
