@@ -323,6 +323,13 @@ def test_deferred_residual_test_reproduces_the_in_launch_one(hp, solvers, monkey
             finally:
                 prob.close()
         (u0_, p0_, lf0, la0), (u1_, p1_, lf1, la1) = res
+        if os.environ.get("FEMFCT_DEEP_HALO", "1") == "0":
+            # shallow halos (a tuning knob): the same sweeps now take one launch more, the last of which the in-launch test
+            # may skip while the deferred one runs it (solve_ctl.h: "the later ones ran nevertheless") -- then the two agree
+            # to the solver tolerance, not to the bit, and the deferred run never did fewer sweeps
+            assert rel(u1_, u0_) < 1e-11 and rel(p1_, p0_) < 1e-11
+            assert np.all(lf1["solver_iters"] >= lf0["solver_iters"]) and np.all(la1["solver_iters"] >= la0["solver_iters"])
+            continue
         assert np.array_equal(u0_, u1_) and np.array_equal(p0_, p1_)
         for a, b in ((lf0, lf1), (la0, la1)):
             # two to four launches, all needed: the case the deferral covers (dt = 1e-3: 3 x 12 or 4 x 10 sweeps)
