@@ -83,7 +83,7 @@ struct femfct_ctx {
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
     int t4_snake = 1;           // walking Jacobi launches alternate their direction (FEMFCT_T4_SNAKE)
-    bool t4_pair = true;        // upwind rows as one value per opposing pair: k_strip8_jacobi_pair_walk, two workgroups per CU (FEMFCT_T4_PAIR)
+    bool t4_pair = true;        // upwind rows as one value per opposing pair: k_strip_jacobi_pair_walk, two workgroups per CU (FEMFCT_T4_PAIR)
     int pair_stagger = 0;       // FEMFCT_PAIR_STAGGER_US * 100: ticks of the 100 MHz clock the second half of the pair walkers waits
     // what the most recent bandwidth-regime launches were (femfct_launch_info): Jacobi kernel (0 none, 1 one workgroup per
     // patch, 2 k_strip4_jacobi_walk, 3 k_strip_jacobi_pair_walk), its walkers, interior Chebyshev patches per side, halo depth

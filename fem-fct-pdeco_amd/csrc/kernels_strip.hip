@@ -1558,7 +1558,7 @@ __device__ __forceinline__ Strip4Node strip4_node(int N, int r, int H, unsigned 
      : (s) == 3 ? w_[r] : (s) == 4 ? ((r) > 0 ? w_[((r) + 3) & 3] : wb_) : ((r) > 0 ? X[((r) + 3) & 3] : BELOW))
 // Accumulation order of the Jacobi rows in the 64-patch family: by opposing pairs -- (E, W), (NE, SW), (N, S).  The
 // upwind low-order operator has at most one non-zero entry per pair (d_ij = max(0, a_ij, a_ji) cancels the other),
-// so k_strip8_jacobi_pair_walk, which keeps ONE value per pair and selects the neighbour, adds the same non-zero
+// so k_strip_jacobi_pair_walk, which keeps ONE value per pair and selects the neighbour, adds the same non-zero
 // terms in the same order: the skipped terms are fma(-0, x, acc) = acc.  Same bits from every kernel of the family.
 #define STRIP4_ROW_FMAS(ACC, LV, X, ABOVE, BELOW, r)                                                \
     _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                              \

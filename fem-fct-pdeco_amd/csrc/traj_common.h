@@ -75,7 +75,7 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         ~RestoreSolver() { c->solver = c->solver_user; c->pair_rows = false; }
     } restore_solver{ctx};
     for (;;) {
-        // bandwidth regime: rows of an upwind operator as one value per opposing pair (k_strip8_jacobi_pair_walk), until a
+        // bandwidth regime: rows of an upwind operator as one value per opposing pair (k_strip_jacobi_pair_walk), until a
         // sweep of this kind shows a row that is not one (FEMFCT_FLAG_ROW_PAIRS below)
         ctx->pair_rows = !ctx->kind_fullrows.count(kind);
         // a kind whose operator lies outside the scheme's dt restriction (Jacobi does not contract: the reference's
