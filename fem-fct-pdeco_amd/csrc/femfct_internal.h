@@ -90,7 +90,7 @@ struct femfct_ctx {
     int32_t last_launch[4] = {0, 0, 0, 0};
     unsigned long long* d_pair_trace = nullptr;   // FEMFCT_PAIR_TRACE=<file>: phase timestamps of the pair walkers, dumped at destroy
     int pair_prio = 0, pair_split = 50;   // FEMFCT_PAIR_PRIO / FEMFCT_PAIR_SPLIT: balance between the two workgroups of a CU (k_strip_jacobi_pair_walk)
-    int pair_shape = 5;         // FEMFCT_PAIR_SHAPE: 0 = 10 rows x 6 waves, 1 = 8 x 6, 2 = 16 x 4, 3 = 8 x 8 (measurement)
+    int pair_shape = 5;         // FEMFCT_PAIR_SHAPE: 5 = 6 rows x 8 waves (the product's), 3 = 8 x 8, 4 = 7 x 8, 6 = 12 x 4 (measurement)
     bool pair_rows = false;     // set by femfct_run_sweep for the sweep in progress: its kind has only shown upwind rows so far
     std::set<int> kind_fullrows;    // sweep kinds that raised FEMFCT_FLAG_ROW_PAIRS: full-row kernels from then on
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)

@@ -2681,17 +2681,14 @@ int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
 // hardware dispatch of one workgroup per patch fills the chip better.
 // pair: the launch is k_strip_jacobi_pair_walk<PAIR_R, PAIR_NST> -- two such workgroups fit a CU, so twice the walkers
 // (but still at least two patches per walker, and the same regime boundary as the 1024-thread walk).
-// shape = rows per thread x waves per workgroup (FEMFCT_PAIR_SHAPE, a measurement knob; 0 is the product's)
+// shape = rows per thread x waves per workgroup (FEMFCT_PAIR_SHAPE, a measurement knob: 3 = 8 x 8, 4 = 7 x 8, 6 = 12 x 4;
+// anything else = the product's 6 x 8; the 6-wave shapes of DESIGN.md section 8 are not compiled in)
 static void pair_shape(const femfct_ctx* ctx, int* R, int* NST) {
     switch (ctx->pair_shape) {
-        case 1: *R = 8; *NST = 6; break;
         case 6: *R = 12; *NST = 4; break;
-        case 7: *R = 14; *NST = 4; break;
-        case 8: *R = 16; *NST = 4; break;
         case 3: *R = 8; *NST = 8; break;
         case 4: *R = 7; *NST = 8; break;
-        case 5: *R = 6; *NST = 8; break;
-        default: *R = 10; *NST = 6; break;
+        default: *R = 6; *NST = 8; break;
     }
 }
 static int pair_tiles_y(const femfct_ctx* ctx, int H) {
@@ -2736,14 +2733,10 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
                            ctx->n, ctx->N, L, b, xa, xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, lmask, npy, \
                            t * npy, ctx->t4_snake ? (launch & 1) : 0, (int64_t)ctx->ws_batch * ctx->W * ctx->n, ctx->pair_stagger, ctx->d_pair_trace, ctx->pair_prio, ctx->pair_split)
         switch (ctx->pair_shape) {
-            case 1: PAIR_LAUNCH(8, 6); break;
             case 6: PAIR_LAUNCH(12, 4); break;
-            case 7: PAIR_LAUNCH(14, 4); break;
-            case 8: PAIR_LAUNCH(16, 4); break;
             case 3: PAIR_LAUNCH(8, 8); break;
             case 4: PAIR_LAUNCH(7, 8); break;
-            case 5: PAIR_LAUNCH(6, 8); break;
-            default: PAIR_LAUNCH(10, 6); break;
+            default: PAIR_LAUNCH(6, 8); break;
         }
 #undef PAIR_LAUNCH
     } else if (walkers > 0) {

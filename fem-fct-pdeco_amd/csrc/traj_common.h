@@ -119,7 +119,7 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         bool short_budget = false, kshort = false, coarse = false, not_pairs = false;
         double worst_res = 0.0, kworst_res = 0.0;
         for (const StepCtl& c : ctx->h_log) not_pairs = not_pairs || (c.flags & FEMFCT_FLAG_ROW_PAIRS);
-        if (not_pairs && !getenv("FEMFCT_PAIR_FORCE")) {             // what the pair-compact launches computed is void: repeat with the full-row kernels
+        if (not_pairs) {             // what the pair-compact launches computed is void: repeat with the full-row kernels
             if (getenv("FEMFCT_DEBUG")) fprintf(stderr, "[femfct] sweep kind %d: rows with both entries of a pair -> full-row Jacobi launches\n", kind);
             ctx->kind_fullrows.insert(kind);
             ctx->log_steps = ctx->log_batch = 0;
