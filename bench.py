@@ -264,6 +264,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
+    # The result stream carries ONE line.  Native libraries write to file descriptor 1 as well (RCCL prints a version banner
+    # on its first communicator): keep the real stdout aside and point fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(res):
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -370,7 +379,7 @@ def main():
         result["data"] = "stub (control-flow rehearsal, not a measurement)"
         ranks.close()
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            emit(result)
         return
 
     log = prob.solver_log(B)
@@ -496,7 +505,7 @@ def main():
         # member, on this node's host cores -- plain CPU children (they import NumPy / SciPy and oracle/ only)
         result["cpu_baseline"] = cpu_baseline_sweep(world, args.workload, min(args.cpu_sample, Nt))
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
 
 
 def cpu_worker(workload, sample, beta_index):
