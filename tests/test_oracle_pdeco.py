@@ -63,3 +63,32 @@ def test_oracle_schnak_time_dependent_wind_reduces_to_stationary():
     q = otraj.solve_schnak_system(c, u0.copy(), v0.copy(), asm, n, Nt, dt, wind=w2, wind_scale=lambda t: 0.0)
     assert np.allclose(p[0], q[0], rtol=0, atol=1e-14) and np.allclose(p[1], q[1], rtol=0, atol=1e-14)
     assert np.abs(a[0] - p[0]).max() > 1e-6
+
+
+def test_solidbody_pgd_loop_records_margins_consistent_with_its_decisions():
+    """oracle.traj.solidbody_pgd_loop (the inline Armijo loop of ..._finaltime_Garvie.py:259-317): a trial is rejected
+    exactly when its recorded margin (J_trial - J_k + gam/s ||c_inc - c||^2_Q) / |J_k| is positive; the search stops at
+    the first accepted trial or after max_armijo trials; both misfit variants."""
+    from oracle.mesh import SquareMesh
+    from oracle.assembly import P1Assembler
+    from oracle import traj as otraj
+    mesh = SquareMesh(-1, 1, 8)
+    asm = P1Assembler(mesh)
+    n, Nt, dt = mesh.nodes, 4, 2e-3
+    tl = (Nt + 1) * n
+    u0 = np.exp(-15 * ((mesh.x + 0.2) ** 2 + (mesh.y - 0.1) ** 2))[mesh.dof_to_vertex]
+    sb = otraj.SolidBody(asm)
+    for optim in ("finaltime", "alltime"):
+        if optim == "alltime":
+            uhat = np.zeros(tl); uhat[:n] = u0
+            otraj.solidbody_forward(sb, 2.0 * np.ones(tl), uhat, n, Nt, dt)
+        else:
+            uhat = np.exp(-15 * ((mesh.x + 0.1) ** 2 + (mesh.y - 0.2) ** 2))[mesh.dof_to_vertex]
+        u, p, c, h = otraj.solidbody_pgd_loop(sb, u0, uhat, np.ones(tl), 0.05, 0.0, 5.0, 3, n, Nt, dt, max_armijo=4, optim=optim)
+        assert u.shape == (tl,) and p.shape == (tl,) and c.shape == (tl,) and np.all((c >= 0.0) & (c <= 5.0))
+        assert len(h["cost"]) == len(h["armijo_k"]) == len(h["armijo_margin"]) == 3
+        for k, ms in zip(h["armijo_k"], h["armijo_margin"]):
+            assert len(ms) == k and 1 <= k <= 4
+            assert all(m > 0 for m in ms[:-1])                  # every trial before the last one looked at was rejected
+            assert ms[-1] <= 0 or k == 4                        # the last one was accepted, or the trials ran out
+        assert h["armijo_margin_min"] == min(abs(m) for ms in h["armijo_margin"] for m in ms)
