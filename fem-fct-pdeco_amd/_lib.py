@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfemfct.so")
+# FEMFCT_LIB: another build of the same library (the -DFEMFCT_TUNING build of `make tuning`); there is still no CPU path
+LIB_PATH = os.environ.get("FEMFCT_LIB") or os.path.join(_HERE, "lib", "libfemfct.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_NOMEM = 0, 1, 2, 3, 4
 FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV = 1, 2, 4, 8

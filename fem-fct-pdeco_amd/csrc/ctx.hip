@@ -137,6 +137,10 @@ int femfct_ensure_workspace(femfct_ctx* ctx, int32_t batch) {
         int rk = femfct_ensure_krylov_ws(ctx, batch);
         if (rk != FEMFCT_OK) return rk;
     }
+#ifdef FEMFCT_TUNING
+    if (!ctx->d_mesh_trace && getenv("FEMFCT_MESH_TRACE"))
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mesh_trace, 16 * sizeof(unsigned long long)));
+#endif
     if (batch <= ctx->ws_batch) return FEMFCT_OK;
     femfct_drop_graphs(ctx);
     size_t nv = (size_t)batch * ctx->n, nm = nv * ctx->W;
@@ -279,6 +283,8 @@ int femfct_install_pattern(femfct_ctx* ctx, int32_t n, int32_t W, const std::vec
     if (const char* e = getenv("FEMFCT_SINGLE_PATCH_BATCH")) { int v = atoi(e); ctx->single_patch_min_batch = v > 0 ? v : (1 << 30); }
     if (const char* e = getenv("FEMFCT_MESH_SOLVE")) ctx->mesh_solve = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_GEOM_MASS")) ctx->geom_mass = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_MESH_STEP")) ctx->mesh_step = atoi(e) != 0;
+    if (const char* e = getenv("FEMFCT_MESH_STEP_BATCH")) ctx->mesh_step_min_batch = std::max(1, atoi(e));
     if (const char* e = getenv("FEMFCT_T4_DPP")) ctx->t4_dpp = atoi(e) != 0;
     if (const char* e = getenv("FEMFCT_T4_K")) ctx->t4_k = std::min(8, std::max(1, atoi(e)));
     if (const char* e = getenv("FEMFCT_SPECIES_SOLVER")) ctx->species_solver = atoi(e);

@@ -66,6 +66,7 @@ struct femfct_ctx {
     int sweep_budget = 48;      // adaptive: sweeps enqueued per step (stand-alone femfct_fct_step)
     std::map<int, int> kind_good;   // last Jacobi budget that sufficed, per kind
     std::map<int, int> kind_fail;   // largest Jacobi budget known to be too small, per kind
+    std::map<int, int> kind_mesh_budget;   // sweep cap of the one-workgroup step, per kind (fixed unless it proved too small)
     std::map<int, int> kind_budget, kind_kbudget;   // per trajectory kind (forward/adjoint of each system)
     bool use_graphs = true;
     // hipGraph replay is held back while a rocprofiler-sdk tool intercepts the HSA queues (rocprofv3 --kernel-trace /
@@ -93,6 +94,11 @@ struct femfct_ctx {
     int pair_shape = 5;         // FEMFCT_PAIR_SHAPE: 5 = 6 rows x 8 waves (the product's), 3 = 8 x 8, 4 = 7 x 8, 6 = 12 x 4 (measurement)
     bool pair_rows = false;     // set by femfct_run_sweep for the sweep in progress: its kind has only shown upwind rows so far
     std::set<int> kind_fullrows;    // sweep kinds that raised FEMFCT_FLAG_ROW_PAIRS: full-row kernels from then on
+    // one workgroup = one trajectory (kernels_mesh.hip): the whole step of a small mesh (N <= 42) in one launch
+    bool mesh_step = true;          // FEMFCT_MESH_STEP
+    int mesh_step_min_batch = 2;    // FEMFCT_MESH_STEP_BATCH: trajectories per launch from which it replaces the tile path
+    bool mesh_step_attr[2] = {false, false};
+    unsigned long long* d_mesh_trace = nullptr;   // FEMFCT_TUNING builds only
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
     int t4_int = 1;             // Chebyshev on the mesh's mass matrix: interior patches by the two-workgroups-per-CU kernel (FEMFCT_T4_INT)
     int t4_walk = 1;            // 64-patch Jacobi: persistent workgroups walk down columns of patches, shared rows carried in LDS (FEMFCT_T4_WALK)
@@ -275,6 +281,11 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
                               int k_first, int k_last, const double* omegas, double md_scale, double* bufA0, double* bufA1,
                               double* bufB0, double* bufB1, int32_t batch,
                               const struct ChebIO* io = nullptr);
+// one workgroup per trajectory (kernels_mesh.hip)
+bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch);
+int femfct_enqueue_mesh_step(femfct_ctx* ctx, struct MatRef A, const double* Nm, int32_t nshared, struct VecRef rhs,
+                             int64_t rhs_bstride, struct VecRef u_n, int64_t u_bstride, double dt, struct VecRef u_out,
+                             int64_t out_bstride, int32_t batch, int32_t budget, bool fuse_end);
 // number of sweeps one fused launch performs (1 when neither tiles nor strips apply)
 int femfct_fused_k(const femfct_ctx* ctx);
 // sweep-budget policy (sweeps to enqueue for the next step sequence)

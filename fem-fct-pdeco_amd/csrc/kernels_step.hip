@@ -645,6 +645,7 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
 
 // the drift-control operator may be derived inside the step kernels instead of being passed as a matrix
 bool femfct_inline_ops_wanted(const femfct_ctx* ctx, int32_t batch) {
+    if (femfct_mesh_step_wanted(ctx, batch)) return false;   // the one-workgroup step takes a stored operator
     return ctx->inline_ops && ctx->structured && ctx->implicit_cols && ctx->W == 7 && femfct_tile4_wanted(ctx, batch);
 }
 
@@ -662,6 +663,14 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
                            int64_t out_bstride, int32_t batch, int32_t budget) {
     if (sb && (!femfct_inline_ops_wanted(ctx, batch) || N))
         return femfct_fail(ctx, FEMFCT_ERR_INVALID, "inline solid-body operator outside its regime");
+    if (!sb && femfct_mesh_step_wanted(ctx, batch)) {
+        // config-sized mesh: the whole step (and its end) in one launch, one workgroup per trajectory
+        const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
+        int r = femfct_enqueue_mesh_step(ctx, A, N, nshared, rhs, rhs_bstride, u_n, u_bstride, dt, u_out, out_bstride, batch,
+                                         budget, fuse_end);
+        if (r == FEMFCT_OK && fuse_end) ctx->end_fused = true;
+        return r;
+    }
     LaunchGeom g = femfct_geom(ctx, batch);
     hipStream_t st = ctx->stream;
     int n = ctx->n, W = ctx->W;

@@ -165,8 +165,9 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
     bool pre = false;
     // step k (level counter k) uses the control of level k+1 (finaltime.py:185): sequence entry k
     // bandwidth regime: the step kernels derive the operator from Arot and the control themselves (no stored A)
-    const bool inl = femfct_inline_ops_wanted(ctx, batch);
+    bool inl = false;
     auto begin = [&]() {
+        inl = femfct_inline_ops_wanted(ctx, batch);     // (inside the sweep driver: depends on the kind's Jacobi kernel)
         if (!inl)
             pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 1, eps, -1.0, rot_scale, bx, by, num_steps,
                                         batch, &Aall);
@@ -218,8 +219,9 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
     int32_t* lv = ctx->d_level;
     MatRef Aall{};
     bool pre = false;
-    const bool inl = femfct_inline_ops_wanted(ctx, batch);
+    bool inl = false;
     auto begin = [&]() {
+        inl = femfct_inline_ops_wanted(ctx, batch);
         // level counter n uses the control of level n (finaltime.py:213): sequence entry n
         if (!inl)
             pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 0, eps, +1.0, rot_scale, bx, by, num_steps,

@@ -39,6 +39,7 @@ template <class F>
 int femfct_run_graph_reps(femfct_ctx* ctx, femfct_ctx::GraphKey key, int reps, int delta, F&& enqueue_one) {
     key.push_back(key_bits((int32_t)reps));
     key.push_back(key_bits((int32_t)ctx->pair_rows));     // a different Jacobi kernel is captured
+    key.push_back(key_bits((int32_t)ctx->solver));
     // delta: the time-level step of this kind of sweep (+1 forward, -1 adjoint).  Step r is enqueued with its level
     // offset baked into every level-indirected reference (lref, MatRef::level_off); the device counters move once, in
     // the last step of the graph -- no per-step ticket / counter update on the critical path of the other R - 1 steps.
@@ -89,7 +90,11 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         const bool cheb = krylov && femfct_species_cheb(ctx, kind);
         const int kkey = cheb ? kind : kind + 1000;
         if (!ctx->kind_kbudget.count(kkey)) ctx->kind_kbudget[kkey] = 40;
-        const int budget = femfct_round_budget(ctx, ctx->kind_budget[kind]);
+        // the one-workgroup step (kernels_mesh.hip) stops by itself: its budget is only a cap, kept fixed so that every sweep
+        // of the kind replays the same captured graphs (a budget that follows the iteration counts would re-capture them)
+        const bool meshp = femfct_mesh_step_wanted(ctx, batch);
+        if (meshp && !ctx->kind_mesh_budget.count(kind)) ctx->kind_mesh_budget[kind] = std::min(ctx->max_iters, 96);
+        const int budget = meshp ? ctx->kind_mesh_budget[kind] : femfct_round_budget(ctx, ctx->kind_budget[kind]);
         const int kbudget = femfct_round_kry_budget(ctx, ctx->kind_kbudget[kkey]);
         int rc = begin();
         if (rc != FEMFCT_OK) return rc;
@@ -146,6 +151,17 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         if (getenv("FEMFCT_DEBUG"))
             fprintf(stderr, "[femfct] sweep kind %d: budget %d (krylov %d) worst %d kworst %d short %d/%d\n", kind, budget,
                     kbudget, worst, kworst, (int)short_budget, (int)kshort);
+        if (!short_budget && !kshort && meshp) {
+            if (krylov)
+                ctx->kind_kbudget[kkey] = std::min(ctx->kry_max_iters, cheb ? std::max(8, kworst + 1)
+                                                                             : std::max(8, kworst + kworst / 4 + 2));
+            return FEMFCT_OK;
+        }
+        if (short_budget && meshp && budget < ctx->max_iters && worst_res < 1.0) {
+            ctx->kind_mesh_budget[kind] = std::min(ctx->max_iters, 2 * budget);
+            short_budget = false;
+            if (!kshort) continue;
+        }
         if (!short_budget && !kshort) {
             ctx->kind_good[kind] = budget;
             ctx->kind_budget[kind] = femfct_next_budget(ctx, worst, coarse);

@@ -1,0 +1,886 @@
+// RECORD, not part of the library (round 4): the one-workgroup-per-trajectory step with 3 x 3 blocks and one value per
+// opposing pair of L -- the only form in which 81 x 81 nodes fit the registers of one CU (3 waves per SIMD, 168 VGPRs).
+// State when it was shelved (MI355X, tools/mesh_step_check.py, smooth control): correct to 1e-13 against the tile path;
+// 135-150 us per step at 81^2 (low-order solve 49 us = 22 sweeps of 2.2 us: most waves hold a node whose row has both
+// entries of a pair and take the pool branch; Chebyshev 21 us; build 33 us with 800-1100 bytes of scratch per lane) against
+// 46 us (B = 1) / 61 us (B = 8) / 158 us (B = 64) on the tile path; the scratch also made launches of 64 workgroups
+// erratic (190-500 us).  DESIGN.md section 8 has the analysis.  Kept for the numbers; it is not compiled by the Makefile.
+// One workgroup = one trajectory: the whole FEM-FCT step of a config-sized mesh (N <= 81 nodes per side) in ONE launch.
+//   FCT_alg_ref                 /root/reference/helpers.py:1715-1872
+//   artificial_diffusion_mat    /root/reference/helpers.py:206-242   (build phase)
+//   spsolve(L, b)               /root/reference/helpers.py:1782      (Jacobi phase, stops by itself)
+//   ChebSI                      /root/reference/helpers.py:143-185   (20 iterations on the mesh's own mass matrix)
+//   Zalesak limiter             /root/reference/helpers.py:1818-1870 (flux phase)
+//
+// Why: on the config meshes (41 x 41, 81 x 81) a step is 46 sweeps over a few thousand nodes.  The tile path runs them as
+// four to seven dependent launches of up to 256 small workgroups; with B trajectories per launch (Armijo trials,
+// helpers.py:1583-1713; the beta copies of advection_solidbody_FCT_PDECO_alltime.py:43-74) those launches reach 2-27 % of
+// the HBM roofline.  Here B trajectories are B workgroups that never wait for each other: the mesh lives in one
+// CU -- matrix rows in registers, the iterate in registers + an LDS image for the neighbours -- and __syncthreads() is
+// the only synchronisation.  HBM traffic per step and trajectory: A once for the build and once for du/dt, the
+// forward half of D out and in, u_n / rhs in, u_{n+1} out.
+//
+// Layout.  A thread owns a BX x BY block of nodes (3 x 3 at 81^2: 27 x 27 = 729 threads; 2 x 2 at 41^2).  In-block
+// neighbours are the thread's own registers; values on the block's rim are published in an LDS image
+// (pitch N + 1 with one shared pad column, pad rows above and below: nodes outside the mesh read 0) and the
+// 2 BX + 2 BY + 2 rim values of the neighbouring blocks are read back after the barrier: 14 reads + 8 writes per 9 nodes
+// and sweep.  Two images alternate, so a sweep needs one barrier.  Blocks that do not touch the mesh boundary are dealt
+// to the first waves, the boundary ring to the last ones: the interior waves run code without existence masks, with
+// constant mass-matrix weights.
+//
+// Every edge quantity that is symmetric or antisymmetric to the bit is computed ONCE, by the node that sees the edge
+// in a forward slot (E, NE, N), and handed to the other end through LDS: d_ij = max(0, a_ij, a_ji), the raw flux
+// f_ij = -f_ji, the limited flux alpha_ij f_ij.  So only the forward half of D exists (in HBM scratch between build
+// and flux phase) and the limiter reads three neighbours' R+- instead of six.
+//
+// Rows of the low-order operator, scaled by 1 / l_ii:
+//   PAIR = false  six off-diagonals per node (any operator).
+//   PAIR = true   one value + one select bit per opposing pair (E, W), (NE, SW), (N, S): the upwind operator
+//                 L = M_L + dt (A - D) of a convection operator has at most one entry per pair;
+//                 Nodes with BOTH entries of a pair exist where a wind component changes sign (the centre of the
+//                 rotation, always; 0.1 - 2 % of the nodes otherwise): their full rows go to a pool in LDS (image 2, idle
+//                 during the solve) and the owning lanes redo those nodes from the pool inside each sweep, in a branch
+//                 that waves without such a node skip.  A pool overflow raises FEMFCT_FLAG_ROW_PAIRS and the sweep is
+//                 repeated on the tile path.
+#include "femfct_internal.h"
+#include "device_utils.h"
+#include "forms.h"
+#include "step_end.h"
+#include "stencil.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <algorithm>
+#include <type_traits>
+
+struct MeshStepArgs {
+    int n, N;               // nodes, nodes per side
+    int TX, TY;             // blocks per side
+    int nint, nint_pad;     // interior blocks, rounded up to whole waves
+    double h, dt;
+    MatRef A;               // flux matrix of this step, ELL slot-major [7][n]
+    const double* Nm;       // non-flux matrix (helpers.py:1775: L += dt N) or null
+    int64_t nm_bs;          // its batch stride (0: shared)
+    VecRef rhs; int64_t rhs_bs;
+    VecRef u_n; int64_t u_bs;
+    VecRef out; int64_t out_bs;
+    const double* ml;       // lumped mass [n]
+    const double* Md;       // diagonal of the consistent mass matrix [n]
+    double* Dh;             // scratch [batch][7][n]: slots 1..3 hold the forward half of D
+    StepCtl* ctl;
+    double rel_tol;
+    int max_sweeps;
+    int dbg_sweeps, dbg_cheb;   // measurement only (FEMFCT_MESH_DBG=sweeps,cheb): exact sweep / iteration counts, results void
+    double om[20];          // Chebyshev weights (helpers.py:170-179)
+    EndArgs e;
+    unsigned long long* trace;   // FEMFCT_TUNING builds: phase timestamps of workgroup 0 (100 MHz), else null
+};
+
+namespace {
+
+constexpr int ms_dx(int s) { return s == 1 || s == 2 ? 1 : (s == 4 || s == 5 ? -1 : 0); }
+constexpr int ms_dy(int s) { return s == 2 || s == 3 ? 1 : (s == 5 || s == 6 ? -1 : 0); }
+
+#define MS_UNROLL _Pragma("unroll")
+// Scheduling fence between the nodes of a thread in the once-per-step phases: left alone, the scheduler interleaves
+// the nine nodes' dependent chains (reciprocals, limiter) and lands 30 registers over the budget of three waves per SIMD;
+// every spilled value there is a scratch round trip with nothing to cover it.
+#define MS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef FEMFCT_TUNING
+#define MS_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MS_STAMP(i) do { } while (0)
+#endif
+
+// keep ? v : +0.0 with v made opaque first: hipcc otherwise sinks the load (or the whole chain) that produced v into a
+// branch of its own around the select -- nine little basic blocks per phase instead of straight-line code
+__device__ __forceinline__ double zsel(bool keep, double v) {
+    asm volatile("" : "+v"(v));
+    return keep ? v : 0.0;
+}
+
+// value of `val` at node (r + DY, c + DX): the thread's own register inside the block, else the image
+template <int BX, int BY, int DX, int DY>
+__device__ __forceinline__ double nb_get(const double (&val)[BY][BX], double* const (&rowp)[BY + 2], int img, int r, int c) {
+    const int rr = r + DY, cc = c + DX;
+    if (rr >= 0 && rr < BY && cc >= 0 && cc < BX) return val[rr][cc];
+    return rowp[rr + 1][img + cc];
+}
+
+// publish `val` at the nodes that a neighbouring block reads with nb_get<DX, DY>
+// (stores are unconditional: a node outside the mesh -- N not a multiple of the block size -- writes to a trash word
+// instead, chosen by an address select; a guarded store would be a branch of its own in the instruction stream)
+template <int BX, int BY, int DX, int DY, class Dst>
+__device__ __forceinline__ void publish(const double (&val)[BY][BX], int img, Dst dst) {
+    MS_UNROLL for (int r = 0; r < BY; ++r) {
+        MS_UNROLL for (int c = 0; c < BX; ++c) {
+            const int rr = r - DY, cc = c - DX;
+            if (rr >= 0 && rr < BY && cc >= 0 && cc < BX) continue;
+            *dst(r, c, img) = val[r][c];
+        }
+    }
+}
+
+// publish the block's rim (every node another block can see)
+template <int BX, int BY, class Dst>
+__device__ __forceinline__ void publish_rim(const double (&val)[BY][BX], int img, Dst dst) {
+    MS_UNROLL for (int r = 0; r < BY; ++r) {
+        MS_UNROLL for (int c = 0; c < BX; ++c) {
+            if (r > 0 && r < BY - 1 && c > 0 && c < BX - 1) continue;
+            *dst(r, c, img) = val[r][c];
+        }
+    }
+}
+
+template <int BX, int BY, class Dst>
+__device__ __forceinline__ void publish_all(const double (&val)[BY][BX], int img, Dst dst) {
+    MS_UNROLL for (int r = 0; r < BY; ++r) {
+        MS_UNROLL for (int c = 0; c < BX; ++c) *dst(r, c, img) = val[r][c];
+    }
+}
+
+// the 2 BX + 2 BY + 2 values around the block (the corners (-1, BX) and (BY, -1) are no neighbours of anything)
+// (volatile: hipcc otherwise pairs neighbouring reads into ds_read2_b64, which gfx950 serves at half the rate of two
+// ds_read_b64 -- MI355X_MICROARCH.md, LDS table: 8 LDS cycles against 2 + 2)
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ double lds_read(const double* p) { return *(volatile lds_double*)p; }
+template <int BX, int BY>
+__device__ __forceinline__ void gather_halo(double (&v)[BY + 2][BX + 2], double* const (&rowp)[BY + 2], int img) {
+    MS_UNROLL for (int c = -1; c < BX; ++c) v[0][c + 1] = lds_read(&rowp[0][img + c]);
+    MS_UNROLL for (int c = 0; c <= BX; ++c) v[BY + 1][c + 1] = lds_read(&rowp[BY + 1][img + c]);
+    MS_UNROLL for (int r = 0; r < BY; ++r) {
+        v[r + 1][0] = lds_read(&rowp[r + 1][img - 1]);
+        v[r + 1][BX + 1] = lds_read(&rowp[r + 1][img + BX]);
+    }
+}
+
+// neighbour (rr, cc) of a node of the block: the thread's own array inside the block, the gathered halo outside
+template <int BX, int BY>
+__device__ __forceinline__ double nbv(const double (&own)[BY][BX], const double (&v)[BY + 2][BX + 2], int rr, int cc) {
+    if (rr >= 0 && rr < BY && cc >= 0 && cc < BX) return own[rr][cc];
+    return v[rr + 1][cc + 1];
+}
+
+// 1 / v to about an ulp: v_rcp_f64 + two Newton steps (the IEEE division sequence costs three times as much, and the
+// fixed part of a step holds five of them per node)
+__device__ __forceinline__ double frcp(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(r, fma(-v, r, 1.0), r);
+    r = fma(r, fma(-v, r, 1.0), r);
+    return r;
+}
+
+// a value every lane holds alike, moved to scalar registers (the reductions' results live across the whole step)
+__device__ __forceinline__ double uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// four reductions (max, min, max, max) behind one barrier pair; every thread gets the results
+template <int NW>
+__device__ __forceinline__ void reduce4(double& a, double& b, double& c, double& d, double* red) {
+    a = wave_reduce(a, OpMax());
+    b = wave_reduce(b, OpMin());
+    c = wave_reduce(c, OpMax());
+    d = wave_reduce(d, OpMax());
+    const int wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    __syncthreads();
+    if (lane == 0) { red[wid] = a; red[NW + wid] = b; red[2 * NW + wid] = c; red[3 * NW + wid] = d; }
+    __syncthreads();
+    double ra = 0.0, rb = INFINITY, rc = 0.0, rd = 0.0;
+    MS_UNROLL for (int w = 0; w < NW; ++w) {
+        ra = fmax(ra, red[w]); rb = fmin(rb, red[NW + w]); rc = fmax(rc, red[2 * NW + w]); rd = fmax(rd, red[3 * NW + w]);
+    }
+    a = uniform(ra); b = uniform(rb); c = uniform(rc); d = uniform(rd);
+}
+
+template <int BX, int BY, int NMAX, int NT, bool PAIR, int NFIX, bool INTERIOR>
+__device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* lds, double* red, int* flg, int bx, int by,
+                                               int bz, int ord) {
+    constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;      // doubles per image
+    constexpr int NC = PAIR ? 3 : 6;
+    constexpr int NW = NT / WAVE;
+    constexpr bool GS = true;             // in-block Gauss-Seidel (false: plain Jacobi; measurement)
+    // NFIX: the config meshes (81, 41 nodes per side) get their own instantiation: every LDS / HBM row offset is then an
+    // immediate and one base register addresses the whole block
+    const int N = NFIX ? NFIX : a.N, n = NFIX ? NFIX * NFIX : a.n, P = N + 1;
+    const int ix0 = bx * BX, iy0 = by * BY;
+    const double dt = a.dt;
+    double* rowp[BY + 2];
+    MS_UNROLL for (int r = -1; r <= BY; ++r) rowp[r + 1] = lds + 1 + (iy0 + r + 1) * P + ix0;
+    bool colok[BX], rowok[BY];
+    MS_UNROLL for (int c = 0; c < BX; ++c) colok[c] = INTERIOR || (ix0 + c < N);
+    MS_UNROLL for (int r = 0; r < BY; ++r) rowok[r] = INTERIOR || (iy0 + r < N);
+    // Threads beyond the blocks of their kind repeat block (1, 1) resp. (0, 0): the same inputs through the same code give
+    // the same bits, so their (unconditional) stores are harmless duplicates.
+    // ALLV: every node of every block lies in the mesh (N a multiple of the block size: 81 = 27 x 3)
+    constexpr bool ALLV = INTERIOR || (NFIX != 0 && NFIX % BX == 0 && NFIX % BY == 0);
+    auto valid = [&](int r, int c) { return ALLV ? true : (rowok[r] && colok[c]); };
+    auto vz = [&](int r, int c, double val) { return ALLV ? val : zsel(valid(r, c), val); };      // 0 outside the mesh
+    const int gi0 = iy0 * N + ix0;
+    auto gidx = [&](int r, int c) { return ALLV ? gi0 + r * N + c : (valid(r, c) ? gi0 + r * N + c : 0); };   // safe to load from
+    double* const trash = reinterpret_cast<double*>(flg + 4);
+    auto dst = [&](int r, int c, int img) -> double* {
+        double* p = &rowp[r + 1][img + c];
+        return ALLV ? p : (valid(r, c) ? p : trash);
+    };
+    // interior nodes: M_L = h^2, m_ii = h^2 / 2, m_ij = h^2 / 12 (six triangles around the node)
+    const double hh = a.h * a.h;
+
+    const double* Ab = mat_ptr(a.A, bz);
+    const double* Nm = a.Nm ? a.Nm + bz * a.nm_bs : nullptr;
+    const double* un = vec_ptr(a.u_n) + bz * a.u_bs;
+    const double* rhs = vec_ptr(a.rhs);
+    if (rhs) rhs += bz * a.rhs_bs;
+    double* out = const_cast<double*>(vec_ptr(a.out)) + bz * a.out_bs;
+    double* Dh = a.Dh + (int64_t)bz * 7 * n;      // (slot 0 is unused: Dh[0] takes the stores of nodes outside the mesh)
+
+    // ------------------------------------------------------------------ build: D, L = M_L + dt (A - D + N), b
+    // Two passes over the thread's nodes, one block row at a time (its loads requested together, then consumed), no LDS:
+    //   1. d_ij = max(0, a_ij, a_ji) for the forward edges (a_ji straight from the neighbour's row), stored at both ends
+    //      of the edge in the HBM scratch (slots 1..3 of the node, 4..6 of its neighbour): the bits are the same at both ends
+    //   2. the row of L from A and D, scaled by 1 / l_ii, and b
+    double x[BY][BX], bp[BY][BX], lc[NC][BY][BX];
+    bool sel[3][BY][BX];
+    double bmax = 0.0, rsmin = INFINITY, ldmax = 0.0;
+    unsigned xm = 0;          // PAIR: nodes of the block with both entries of a pair (bit r * BX + c)
+    auto fwd_exists = [&](int r, int c, int s) -> bool {      // the neighbour in forward slot s (1..3) is a mesh node
+        if (INTERIOR) return true;
+        const int gxn = ix0 + c, gyn = iy0 + r;
+        return (ms_dx(s) == 0 || gxn < N - 1) && (ms_dy(s) == 0 || gyn < N - 1) && valid(r, c);
+    };
+    MS_UNROLL for (int r = 0; r < BY; ++r) {
+        double af[3][BX], at[3][BX];
+        MS_UNROLL for (int c = 0; c < BX; ++c)
+            MS_UNROLL for (int s = 1; s <= 3; ++s) {
+                const int i = gidx(r, c), j = fwd_exists(r, c, s) ? i + ms_dx(s) + ms_dy(s) * N : i;
+                af[s - 1][c] = (Ab + (int64_t)s * n)[i];
+                at[s - 1][c] = (Ab + (int64_t)(s + 3) * n)[j];
+            }
+        if (r == 0) {
+            // (the first loads are in flight while the images are cleared: nodes outside the mesh read 0 from them)
+            for (int kz = threadIdx.x; kz < 3 * IMG; kz += NT) lds[kz] = 0.0;
+            if (threadIdx.x < 4) flg[threadIdx.x] = 0;         // three residual flags, then the pool counter
+        }
+        MS_FENCE();
+        MS_UNROLL for (int c = 0; c < BX; ++c)
+            MS_UNROLL for (int s = 1; s <= 3; ++s) {
+                const bool ex = fwd_exists(r, c, s);
+                const int i = gidx(r, c), j = ex ? i + ms_dx(s) + ms_dy(s) * N : 0;
+                const double d = INTERIOR ? fmax(0.0, fmax(af[s - 1][c], at[s - 1][c]))
+                                          : (ex ? fmax(0.0, fmax(af[s - 1][c], at[s - 1][c])) : 0.0);
+                (Dh + (ALLV || valid(r, c) ? (int64_t)s * n : 0))[i] = d;
+                (Dh + (ex ? (int64_t)(s + 3) * n : 0))[j] = d;
+            }
+        MS_FENCE();
+    }
+    // (a node without a backward neighbour keeps what the previous step left in its backward slots: cleared here)
+    if (!INTERIOR) {
+        MS_UNROLL for (int r = 0; r < BY; ++r)
+            MS_UNROLL for (int c = 0; c < BX; ++c)
+                MS_UNROLL for (int s = 1; s <= 3; ++s) {
+                    const int gxn = ix0 + c, gyn = iy0 + r;
+                    const bool hasb = (ms_dx(s) == 0 || gxn > 0) && (ms_dy(s) == 0 || gyn > 0);
+                    if (!hasb && valid(r, c)) (Dh + (int64_t)(s + 3) * n)[gidx(r, c)] = 0.0;
+                }
+    }
+    __syncthreads();
+    MS_STAMP(1);
+    MS_UNROLL for (int r = 0; r < BY; ++r) {
+        double am[7][BX], dm[6][BX], uv[BX], rb[BX], mlv0[BX], nm[7][BX];
+        MS_UNROLL for (int c = 0; c < BX; ++c) {
+            const int i = gidx(r, c);
+            MS_UNROLL for (int s = 0; s < 7; ++s) { am[s][c] = (Ab + (int64_t)s * n)[i]; nm[s][c] = 0.0; }
+            MS_UNROLL for (int s = 1; s < 7; ++s) dm[s - 1][c] = (Dh + (int64_t)s * n)[i];
+            uv[c] = un[i]; rb[c] = 0.0; mlv0[c] = hh;
+            if (!INTERIOR) mlv0[c] = a.ml[i];
+        }
+        if (rhs) {
+            MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = rhs[gidx(r, c)];
+        }
+        if (!PAIR && Nm) {
+            MS_UNROLL for (int c = 0; c < BX; ++c)
+                MS_UNROLL for (int s = 0; s < 7; ++s) nm[s][c] = (Nm + (int64_t)s * n)[gidx(r, c)];
+        }
+        MS_FENCE();
+        MS_UNROLL for (int c = 0; c < BX; ++c) {
+            const bool vv = valid(r, c);
+            double dsum = 0.0, lrow[6];
+            MS_UNROLL for (int p = 0; p < 3; ++p) {
+                const int s = p + 1, o = p + 4;
+                const double df = vz(r, c, dm[s - 1][c]), db = vz(r, c, dm[o - 1][c]);
+                dsum += df + db;
+                double lf = dt * (vz(r, c, am[s][c]) - df), lb = dt * (vz(r, c, am[o][c]) - db);
+                if (!PAIR) { lf += vz(r, c, dt * nm[s][c]); lb += vz(r, c, dt * nm[o][c]); }
+                lrow[p] = lf; lrow[3 + p] = lb;
+            }
+            const double mli = INTERIOR ? hh : (ALLV ? mlv0[c] : zsel(vv, mlv0[c] - 1.0) + 1.0);
+            const double ui = vz(r, c, uv[c]);
+            double ld = mli + dt * (vz(r, c, am[0][c]) + dsum);
+            if (!PAIR) ld += vz(r, c, dt * nm[0][c]);
+            const double bi = mli * ui + vz(r, c, dt * rb[c]);
+            const double rinv = frcp(ld);
+            MS_UNROLL for (int p = 0; p < 3; ++p) {
+                if (PAIR) {
+                    const bool tb = lrow[3 + p] != 0.0;
+                    if (tb && lrow[p] != 0.0) xm |= 1u << (r * BX + c);
+                    lc[p][r][c] = (tb ? lrow[3 + p] : lrow[p]) * rinv;
+                    sel[p][r][c] = tb;
+                } else {
+                    lc[p][r][c] = lrow[p] * rinv;
+                    lc[NC - 3 + p][r][c] = lrow[3 + p] * rinv;
+                    sel[p][r][c] = false;
+                }
+            }
+            bmax = fmax(bmax, fabs(bi));
+            bp[r][c] = bi * rinv;
+            ldmax = fmax(ldmax, ld);
+            x[r][c] = ui;
+        }
+        MS_FENCE();
+    }
+    MS_STAMP(2);
+    // PAIR: full rows of the nodes in xm -> pool records {l_E, l_W, l_NE, l_SW, l_N, l_S, b} / l_ii in image 2
+    constexpr int POOL_REC = 8, POOL_CAP = IMG / POOL_REC;
+    double* const pool = lds + 2 * IMG;
+    int xbase = 0;
+    double xcode = 0.0;            // 1: the block has such nodes, 2: ... and the pool is full
+    if (PAIR && xm) {
+        xcode = 1.0;
+        xbase = atomicAdd(&flg[3], __popc(xm));
+        if (xbase + __popc(xm) > POOL_CAP) { xcode = 2.0; xm = 0; }
+        int rk = 0;
+        for (unsigned m = xm; m; m &= m - 1, ++rk) {
+            const int kq = __ffs(m) - 1, r = kq / BX, c = kq - r * BX;
+            const int i = gi0 + r * N + c;
+            double l6[6], dsm = 0.0;
+            MS_UNROLL for (int pq = 0; pq < 3; ++pq) {
+                const int sf = pq + 1, sb = pq + 4;
+                const double af = Ab[(int64_t)sf * n + i], ab = Ab[(int64_t)sb * n + i];
+                const double df = Dh[(int64_t)sf * n + i], db = Dh[(int64_t)sb * n + i];
+                dsm += df + db;
+                l6[2 * pq] = dt * (af - df);
+                l6[2 * pq + 1] = dt * (ab - db);
+            }
+            const double mli = a.ml[i];
+            const double ld = mli + dt * (Ab[i] + dsm);
+            const double rinv = frcp(ld);
+            double* rec = pool + (xbase + rk) * POOL_REC;
+            MS_UNROLL for (int qq = 0; qq < 6; ++qq) rec[qq] = l6[qq] * rinv;
+            rec[6] = (mli * un[i] + (rhs ? dt * rhs[i] : 0.0)) * rinv;
+        }
+    }
+    reduce4<NW>(bmax, rsmin, ldmax, xcode, red);
+    // Residual test: |r_i| = l_ii |x_i' - x_i| <= max_j l_jj |x_i' - x_i| -- the per-node diagonal would cost nine more
+    // registers in the sweep loop; the bound can only ask for a sweep more, never for one less.
+    const double tolb = a.rel_tol * bmax, tolx = uniform(tolb / ldmax);
+    const bool anyexc = PAIR && xcode != 0.0;
+    MS_STAMP(3);
+    int iters = 0, sflags = 0;
+    double resid = 0.0;
+    if (PAIR && xcode > 1.0) {
+        // far from an upwind operator: more such nodes than the pool holds -- report, leave u_out alone (the host repeats
+        // the sweep on the tile path)
+        sflags |= FEMFCT_FLAG_ROW_PAIRS;
+    } else {
+        // -------------------------------------------------------------- low-order solve: Jacobi until ||b - L x|| <= tol ||b||
+        publish_rim<BX, BY>(x, 0, dst);
+        __syncthreads();
+        double v[BY + 2][BX + 2];         // halo of the current iterate (its rim is in image `cur`)
+        double rmx = 0.0;
+        // one sweep: x <- D^-1 (b - O x) from the halo in v; publishes the new rim in img_out.  Sweep k raises flag k % 3
+        // when its input missed the tolerance; the flag is looked at after the NEXT gather has been issued, so the
+        // read does not add a round trip of its own to the sweep.
+        // Inside the block a node takes the values its in-block neighbours have just got (block Gauss-Seidel, never slower
+        // than Jacobi for an M-matrix: the iterate is updated in place); successive sweeps run through the block in
+        // opposite orders so that every wind direction is followed by one of them.  Across blocks it stays Jacobi: nothing
+        // crosses a barrier early.  A node whose row does not fit the pair form is redone from its pool record at its turn
+        // (a branch that only the waves holding such a node at that position take).
+        // (the sweep exists twice: waves without a pool node run the copy that has no trace of the pool)
+        const bool wave_pooled = PAIR && anyexc && __builtin_amdgcn_readfirstlane((int)__any(xm != 0u)) != 0;
+        // The halo is read block row by block row, just ahead of the row that needs it (a fence after every row keeps the
+        // scheduler from pulling all 14 reads to the top: the sweep then fits the registers of three waves per SIMD).
+        // Stage for row r, rows ascending: its W value, the E value of row r + 1 (NE of the last column), with the first
+        // row the whole bottom halo row and its own E value, with the last row the top halo row.  Rows descending: mirrored.
+        auto stage = [&](const int img_in, const int r, auto revtag) {
+            constexpr bool rev = decltype(revtag)::value;
+            auto ld = [&](int hr, int hc) { v[hr][hc] = lds_read(&rowp[hr][img_in + hc - 1]); };    // v[hr][hc] = node (hr - 1, hc - 1)
+            if (!rev) {
+                ld(r + 1, 0);
+                if (r + 2 <= BY) ld(r + 2, BX + 1);
+                if (r == 0) {
+                    MS_UNROLL for (int hc = 0; hc <= BX; ++hc) ld(0, hc);
+                    ld(1, BX + 1);
+                }
+                if (r == BY - 1) {
+                    MS_UNROLL for (int hc = 1; hc <= BX + 1; ++hc) ld(BY + 1, hc);
+                }
+            } else {
+                ld(r + 1, BX + 1);
+                if (r >= 1) ld(r, 0);
+                if (r == BY - 1) {
+                    MS_UNROLL for (int hc = 1; hc <= BX + 1; ++hc) ld(BY + 1, hc);
+                    ld(BY, 0);
+                }
+                if (r == 0) {
+                    MS_UNROLL for (int hc = 0; hc <= BX; ++hc) ld(0, hc);
+                }
+            }
+        };
+        // returns 0: swept; 1: the previous sweep's input had met the tolerance (x is the solution); 2: out of budget
+        auto sweep_body = [&](const int img_in, const int img_out, const int k, auto revtag, auto pooltag) -> int {
+            constexpr bool rev = decltype(revtag)::value, pooled = decltype(pooltag)::value;
+            stage(img_in, rev ? BY - 1 : 0, revtag);
+            if (k > 0) {
+                // (the flag is requested behind the first halo values: no round trip of its own)
+                const bool done = (*(volatile int*)&flg[(k - 1) % 3] == 0) && k >= a.dbg_sweeps;
+                if (done) return 1;
+            }
+            if (k >= a.max_sweeps) return 2;
+            rmx = 0.0;
+            MS_UNROLL for (int t = 0; t < BY; ++t) {
+                const int r = rev ? BY - 1 - t : t;
+                if (t > 0) stage(img_in, r, revtag);
+                MS_UNROLL for (int u = 0; u < BX; ++u) {
+                    const int c = rev ? BX - 1 - u : u, qq = r * BX + c;
+                    auto nb = [&](int dy, int dx) -> double { return nbv<BX, BY>(x, v, r + dy, c + dx); };
+                    double acc = bp[r][c];
+                    if (PAIR) {
+                        // (E, W), (NE, SW), (N, S): the accumulation order of the whole 64-patch family
+                        acc = fma(-lc[0][r][c], sel[0][r][c] ? nb(0, -1) : nb(0, 1), acc);
+                        acc = fma(-lc[1][r][c], sel[1][r][c] ? nb(-1, -1) : nb(1, 1), acc);
+                        acc = fma(-lc[2][r][c], sel[2][r][c] ? nb(-1, 0) : nb(1, 0), acc);
+                        if (pooled) {
+                            if ((xm >> qq) & 1u) {
+                                const double* rec = pool + (xbase + __popc(xm & ((1u << qq) - 1u))) * POOL_REC;
+                                double a2 = rec[6];
+                                a2 = fma(-rec[0], nb(0, 1), a2);
+                                a2 = fma(-rec[1], nb(0, -1), a2);
+                                a2 = fma(-rec[2], nb(1, 1), a2);
+                                a2 = fma(-rec[3], nb(-1, -1), a2);
+                                a2 = fma(-rec[4], nb(1, 0), a2);
+                                a2 = fma(-rec[5], nb(-1, 0), a2);
+                                acc = a2;
+                            }
+                        }
+                    } else {
+                        acc = fma(-lc[0][r][c], nb(0, 1), acc);
+                        acc = fma(-lc[NC - 3][r][c], nb(0, -1), acc);
+                        acc = fma(-lc[1][r][c], nb(1, 1), acc);
+                        acc = fma(-lc[NC - 2][r][c], nb(-1, -1), acc);
+                        acc = fma(-lc[2][r][c], nb(1, 0), acc);
+                        acc = fma(-lc[NC - 1][r][c], nb(-1, 0), acc);
+                    }
+                    acc = vz(r, c, acc);
+                    rmx = fmax(rmx, fabs(acc - x[r][c]));      // the bound of |r_i| / l_ii this sweep goes by
+                    x[r][c] = acc;
+                }
+                MS_FENCE();
+            }
+            publish_rim<BX, BY>(x, img_out, dst);
+            const bool viol = rmx > tolx;
+            if (__any(viol) && (threadIdx.x % WAVE) == 0) flg[k % 3] = 1;
+            if (threadIdx.x == 0) flg[(k + 1) % 3] = 0;
+            __syncthreads();
+            return 0;
+        };
+        auto sweep = [&](const int img_in, const int img_out, const int k, auto revtag) -> int {
+            if (PAIR && wave_pooled) return sweep_body(img_in, img_out, k, revtag, std::true_type{});
+            return sweep_body(img_in, img_out, k, revtag, std::false_type{});
+        };
+        int k = 0, cur = 0, st = 0;
+        for (;;) {
+            st = sweep(0, IMG, k, std::false_type{});
+            if (st) { cur = 0; break; }
+            ++k;
+            st = sweep(IMG, 0, k, std::true_type{});
+            if (st) { cur = 1; break; }
+            ++k;
+        }
+        const bool conv = st == 1;
+        gather_halo<BX, BY>(v, rowp, cur ? IMG : 0);       // (the halo of the solution, for du/dt)
+        iters = k;
+        MS_STAMP(4);
+        if (!conv) sflags |= FEMFCT_FLAG_SOLVER_BUDGET;
+
+        // -------------------------------------------------------------- du/dt: r = rhs - A u_L, then ChebSI on M
+        // (x = u_L with its halo in v; u_L's rim is kept in image 2 for the flux phase.)
+        double zb[BY][BX], ym[BY][BX], yo[BY][BX];
+        double rw[BY][BX];                // boundary ring: 1 / (2.5 ntri) of the node (mass-matrix weights cnt_ij / (2.5 ntri))
+        bool ex[BY][BX], ey[BY][BX];      // ... and whether its E / W resp. N / S edges lie on the mesh boundary (cnt = 1)
+        {
+            MS_UNROLL for (int r = 0; r < BY; ++r) {
+                // one block row at a time: its 7 x BX matrix entries are requested together, then consumed
+                double ar[7][BX], rd[BX], mdv[BX], nsum[BX];
+                MS_UNROLL for (int c = 0; c < BX; ++c) {
+                    const int i = gidx(r, c);
+                    MS_UNROLL for (int s = 0; s < 7; ++s) ar[s][c] = (Ab + (int64_t)s * n)[i];
+                    rd[c] = 0.0; mdv[c] = 0.5 * hh; nsum[c] = 0.0;
+                    if (!INTERIOR) mdv[c] = a.Md[i];
+                }
+                if (!PAIR && Nm) {
+                    MS_UNROLL for (int c = 0; c < BX; ++c)
+                        MS_UNROLL for (int s = 0; s < 7; ++s) nsum[c] += (Nm + (int64_t)s * n)[gidx(r, c)];
+                }
+                if (rhs) {
+                    MS_UNROLL for (int c = 0; c < BX; ++c) rd[c] = rhs[gidx(r, c)];
+                }
+                MS_FENCE();
+                MS_UNROLL for (int c = 0; c < BX; ++c) {
+                    const bool vv = valid(r, c);
+                    double acc = ar[0][c] * x[r][c], asum = ar[0][c];
+                    MS_UNROLL for (int s = 1; s < 7; ++s) {
+                        acc = fma(ar[s][c], nbv<BX, BY>(x, v, r + ms_dy(s), c + ms_dx(s)), acc);
+                        asum += ar[s][c];
+                    }
+                    // row sum of L = M_L + dt (A - D + N): D's rows sum to zero, so it is M_L + dt sum_j (a_ij + n_ij)
+                    // (helpers.py:1796-1809 sums the dense matrix; only the sign and the minimum are used)
+                    {
+                        const double mlr = INTERIOR ? hh : 2.0 * mdv[c];      // M_L = 2 m_ii on this mesh
+                        const double rs = mlr + dt * (asum + nsum[c]);
+                        rsmin = vv ? fmin(rsmin, rs) : rsmin;
+                    }
+                    double rr = -acc + rd[c];
+                    if (INTERIOR) {
+                        zb[r][c] = rr * (1.6 / hh);                  // 1 / (1.25 m_ii), m_ii = h^2 / 2
+                    } else {
+                        rr = vz(r, c, rr);
+                        zb[r][c] = rr * frcp(1.25 * mdv[c]);
+                        // m_ij / (1.25 m_ii) = cnt_ij / (2.5 ntri): cnt = 2 for an edge inside the mesh, 1 on its boundary
+                        const int gxn = ix0 + c, gyn = iy0 + r, nc = N - 1;
+                        const int c00 = (gxn < nc && gyn < nc), c10 = (gxn > 0 && gyn < nc), c01 = (gxn < nc && gyn > 0),
+                                  c11 = (gxn > 0 && gyn > 0);
+                        const int ntri = 2 * c00 + c10 + c01 + 2 * c11;
+                        rw[r][c] = zsel(vv && ntri > 0, frcp(2.5 * (double)max(ntri, 1)));
+                        ex[r][c] = (gyn == 0 || gyn == nc);
+                        ey[r][c] = (gxn == 0 || gxn == nc);
+                    }
+                    ym[r][c] = a.om[0] * zb[r][c];
+                    yo[r][c] = 0.0;
+                }
+                MS_FENCE();
+            }
+        }
+        if (anyexc) {          // image 2 goes back to being an image (nodes outside the mesh read 0); `resid` rides along
+            __syncthreads();
+            for (int kz = threadIdx.x; kz < IMG; kz += NT) pool[kz] = 0.0;
+        }
+        {
+            double r0 = rmx, r2 = 0.0, r3 = 0.0;
+            reduce4<NW>(r0, rsmin, r2, r3, red);
+            resid = bmax > 0.0 ? r0 * ldmax / bmax : 0.0;     // (an upper bound of ||r|| / ||b||: see the test)
+            if (!(rsmin > 0.0)) sflags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
+        }
+        publish_rim<BX, BY>(x, 2 * IMG, dst);
+        MS_STAMP(5);
+        int q = cur ^ 1;          // image the next iterate's rim goes to
+        // y_k in ym, y_(k-1) in yo; an iteration overwrites y_(k-1) with y_(k+1) and the two arrays swap roles
+        auto cheb = [&](double (&ycur)[BY][BX], double (&yold)[BY][BX], const int it) {
+            publish_rim<BX, BY>(ycur, q ? IMG : 0, dst);
+            __syncthreads();
+            gather_halo<BX, BY>(v, rowp, q ? IMG : 0);
+            const double om = a.om[(it - 1) % 20];
+            MS_UNROLL for (int r = 0; r < BY; ++r)
+                MS_UNROLL for (int c = 0; c < BX; ++c) {
+                    const double sx = nbv<BX, BY>(ycur, v, r, c + 1) + nbv<BX, BY>(ycur, v, r, c - 1),
+                                 sd = nbv<BX, BY>(ycur, v, r + 1, c + 1) + nbv<BX, BY>(ycur, v, r - 1, c - 1),
+                                 sy = nbv<BX, BY>(ycur, v, r + 1, c) + nbv<BX, BY>(ycur, v, r - 1, c);
+                    // z = (b - M y) / (1.25 m_ii) = zb - 0.8 y - sum_j w_ij y_j;  y' = om (z + y - y_old) + y_old
+                    double z;
+                    if (INTERIOR) {
+                        z = fma(-2.0 / 15.0, (sx + sd) + sy, zb[r][c]);
+                    } else {
+                        const double t = ((ex[r][c] ? sx : sx + sx) + (sd + sd)) + (ey[r][c] ? sy : sy + sy);
+                        z = fma(-rw[r][c], t, zb[r][c]);
+                    }
+                    yold[r][c] = fma(om, fma(0.2, ycur[r][c], z) - yold[r][c], yold[r][c]);
+                }
+            q ^= 1;
+        };
+        int it = 2;
+        for (; it + 1 <= a.dbg_cheb; it += 2) {
+            cheb(ym, yo, it);
+            cheb(yo, ym, it + 1);
+        }
+        if (it <= a.dbg_cheb) {          // an even number of iterations in all: the result ends up in yo
+            cheb(ym, yo, it);
+            MS_UNROLL for (int r = 0; r < BY; ++r)
+                MS_UNROLL for (int c = 0; c < BX; ++c) ym[r][c] = yo[r][c];
+        }
+        MS_STAMP(6);
+        // ym = du/dt.  Flux phase; images: 2 = u_L rim, q = du/dt rim (published now)
+        publish_rim<BX, BY>(ym, q ? IMG : 0, dst);
+        __syncthreads();
+
+        // -------------------------------------------------------------- fluxes, Zalesak limiter, update
+        double ff[3][BY][BX], qp[BY][BX], qm[BY][BX];
+        {
+            // forward fluxes first (u_L, du/dt of the E, NE, N neighbours), then the bounds (all six u_L): the register
+            // budget of 3 waves per SIMD holds one of the two halo sets at a time
+            gather_halo<BX, BY>(v, rowp, 2 * IMG);
+            {
+                const double mq = (0.5 * hh) / 12.0;
+                const int qi = q ? IMG : 0;
+                MS_UNROLL for (int r = 0; r < BY; ++r)
+                    MS_UNROLL for (int c = 0; c < BX; ++c) {
+                        const bool vv = valid(r, c);
+                        const int i = gidx(r, c);
+                        int pc = 0;
+                        if (!INTERIOR) pc = mass_edge_counts(ix0 + c, iy0 + r, N - 1);
+                        MS_UNROLL for (int s = 1; s <= 3; ++s) {
+                            const double duj = s == 1 ? nb_get<BX, BY, 1, 0>(ym, rowp, qi, r, c)
+                                             : s == 2 ? nb_get<BX, BY, 1, 1>(ym, rowp, qi, r, c)
+                                                      : nb_get<BX, BY, 0, 1>(ym, rowp, qi, r, c);
+                            const double mij = INTERIOR ? 2.0 * mq : (double)((pc >> (2 * (s - 1))) & 3) * mq;
+                            const double dij = vz(r, c, (Dh + (int64_t)s * n)[i]);
+                            const double fs = mij * (ym[r][c] - duj) + dij * (x[r][c] - nbv<BX, BY>(x, v, r + ms_dy(s), c + ms_dx(s)));
+                            ff[s - 1][r][c] = vz(r, c, fs);
+                        }
+                    }
+            }
+            MS_UNROLL for (int r = 0; r < BY; ++r)
+                MS_UNROLL for (int c = 0; c < BX; ++c) {
+                    const double ui = x[r][c];
+                    double umax = ui, umin = ui;
+                    int pc = 0;
+                    if (!INTERIOR) pc = valid(r, c) ? mass_edge_counts(ix0 + c, iy0 + r, N - 1) : 0;
+                    MS_UNROLL for (int s = 1; s < 7; ++s) {
+                        const double uj = nbv<BX, BY>(x, v, r + ms_dy(s), c + ms_dx(s));
+                        const bool exists = INTERIOR || ((pc >> (2 * (s - 1))) & 3) != 0;
+                        umax = exists ? fmax(umax, uj) : umax;
+                        umin = exists ? fmin(umin, uj) : umin;
+                    }
+                    qp[r][c] = umax - ui;
+                    qm[r][c] = umin - ui;
+                }
+        }
+        MS_STAMP(7);
+        __syncthreads();       // every rim of u_L and du/dt has been read: the three images take the forward fluxes
+        publish<BX, BY, -1, 0>(ff[0], 0, dst);
+        publish<BX, BY, -1, -1>(ff[1], IMG, dst);
+        publish<BX, BY, 0, -1>(ff[2], 2 * IMG, dst);
+        __syncthreads();
+        double rp[BY][BX], rm[BY][BX], rml[BY][BX];      // R+, R-, dt / M_L
+        MS_UNROLL for (int r = 0; r < BY; ++r)
+            MS_UNROLL for (int c = 0; c < BX; ++c) rml[r][c] = INTERIOR ? dt / hh : a.ml[gidx(r, c)];
+        if (!INTERIOR) {
+            MS_FENCE();
+            MS_UNROLL for (int r = 0; r < BY; ++r)
+                MS_UNROLL for (int c = 0; c < BX; ++c) { rml[r][c] = dt * frcp(rml[r][c]); MS_FENCE(); }
+        }
+        MS_UNROLL for (int r = 0; r < BY; ++r)
+            MS_UNROLL for (int c = 0; c < BX; ++c) {
+                // backward slots: f_ij = -f_ji, the bits the neighbour computed
+                const double fw = -nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c);
+                const double fsw = -nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c);
+                const double fs = -nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c);
+                double pp = 0.0, pm = 0.0;
+                MS_UNROLL for (int s = 0; s < 3; ++s) { pp += fmax(ff[s][r][c], 0.0); pm += fmin(ff[s][r][c], 0.0); }
+                pp += fmax(fw, 0.0); pm += fmin(fw, 0.0);
+                pp += fmax(fsw, 0.0); pm += fmin(fsw, 0.0);
+                pp += fmax(fs, 0.0); pm += fmin(fs, 0.0);
+                // R+- = min(1, M_L Q+- / (dt P+-))
+                rp[r][c] = (pp != 0.0) ? fmin(1.0, qp[r][c] * frcp(rml[r][c] * pp)) : 1.0;
+                rm[r][c] = (pm != 0.0) ? fmin(1.0, qm[r][c] * frcp(rml[r][c] * pm)) : 1.0;
+                MS_FENCE();
+            }
+        __syncthreads();
+        publish_rim<BX, BY>(rp, 0, dst);
+        publish_rim<BX, BY>(rm, IMG, dst);
+        __syncthreads();
+        MS_STAMP(8);
+        double fbar[BY][BX];
+        MS_UNROLL for (int r = 0; r < BY; ++r)
+            MS_UNROLL for (int c = 0; c < BX; ++c) {
+                double acc = 0.0;
+                MS_UNROLL for (int s = 0; s < 3; ++s) {
+                    const double rpj = s == 0 ? nb_get<BX, BY, 1, 0>(rp, rowp, 0, r, c)
+                                     : s == 1 ? nb_get<BX, BY, 1, 1>(rp, rowp, 0, r, c)
+                                              : nb_get<BX, BY, 0, 1>(rp, rowp, 0, r, c);
+                    const double rmj = s == 0 ? nb_get<BX, BY, 1, 0>(rm, rowp, IMG, r, c)
+                                     : s == 1 ? nb_get<BX, BY, 1, 1>(rm, rowp, IMG, r, c)
+                                              : nb_get<BX, BY, 0, 1>(rm, rowp, IMG, r, c);
+                    const double f = ff[s][r][c];
+                    const double al = (f > 0.0) ? fmin(rp[r][c], rmj) : fmin(rm[r][c], rpj);
+                    ff[s][r][c] = al * f;                 // limited flux of the forward edge
+                    acc += ff[s][r][c];
+                }
+                fbar[r][c] = acc;
+                MS_FENCE();
+            }
+        __syncthreads();
+        publish<BX, BY, -1, 0>(ff[0], 0, dst);
+        publish<BX, BY, -1, -1>(ff[1], IMG, dst);
+        publish<BX, BY, 0, -1>(ff[2], 2 * IMG, dst);
+        __syncthreads();
+        MS_UNROLL for (int r = 0; r < BY; ++r)
+            MS_UNROLL for (int c = 0; c < BX; ++c) {
+                double acc = fbar[r][c];
+                acc -= nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c);
+                acc -= nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c);
+                acc -= nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c);
+                (ALLV || valid(r, c) ? out : Dh)[gidx(r, c)] = fma(rml[r][c], acc, x[r][c]);
+            }
+    }
+
+    MS_STAMP(9);
+#ifdef FEMFCT_TUNING
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[11] = __builtin_readcyclecounter();
+#endif
+    // ------------------------------------------------------------------ solver record, log
+    if (threadIdx.x == 0) {
+        StepCtl rec;
+        rec.flags = sflags; rec.iters = iters; rec.done = 1; rec.parity = 0;
+        rec.resid = resid; rec.bnorm = bmax; rec.min_rowsum = rsmin; rec.rs[0] = rec.rs[1] = 0.0; rec.pad = 0.0;
+        a.ctl[bz] = rec;
+        if (a.e.level) a.e.log[(int64_t)ord * a.e.batch + bz] = rec;
+    }
+    if (a.e.level && a.e.kctl) {
+        const uint32_t* ks = reinterpret_cast<const uint32_t*>(a.e.kctl + bz);
+        uint32_t* kd = reinterpret_cast<uint32_t*>(a.e.klog + (int64_t)ord * a.e.batch + bz);
+        if (threadIdx.x < 16) kd[threadIdx.x] = ks[threadIdx.x];
+    }
+}
+
+template <int BX, int BY, int NMAX, int NT, bool PAIR, int NFIX>
+__global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
+    extern __shared__ double lds[];
+    constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;
+    double* red = lds + 3 * IMG;                         // 4 * NT / 64 doubles
+    int* flg = reinterpret_cast<int*>(red + 4 * (NT / WAVE));   // 4 ints, then one trash double
+    const int bz = blockIdx.x, tid = threadIdx.x;
+    // time level and log ordinal are read before anything else (the last workgroup of the graph's last step moves them)
+    const int ord = a.e.level ? a.e.level[1] + a.e.ord_off : 0;
+    MS_STAMP(0);
+#ifdef FEMFCT_TUNING
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[10] = __builtin_readcyclecounter();
+#endif
+    // interior blocks first (whole waves), the boundary ring behind them
+    // (spare threads repeat block (1, 1) of the interior resp. block (0, 0) of the ring)
+    int bx = 1, by = 1;
+    const int TXi = a.TX - 2;
+    if (tid < a.nint) {
+        by = tid / TXi; bx = tid - by * TXi + 1; by += 1;
+    } else if (tid >= a.nint_pad) {
+        const int kk = tid - a.nint_pad, nb = 2 * a.TX + 2 * (a.TY - 2);
+        bx = 0; by = 0;
+        if (kk < a.TX) { bx = kk; }
+        else if (kk < 2 * a.TX) { bx = kk - a.TX; by = a.TY - 1; }
+        else if (kk < nb) { const int k2 = kk - 2 * a.TX; by = 1 + (k2 >> 1); bx = (k2 & 1) ? a.TX - 1 : 0; }
+    }
+    if (tid < a.nint_pad) mesh_step_body<BX, BY, NMAX, NT, PAIR, NFIX, true>(a, lds, red, flg, bx, by, bz, ord);
+    else mesh_step_body<BX, BY, NMAX, NT, PAIR, NFIX, false>(a, lds, red, flg, bx, by, bz, ord);
+    // the graph's last step moves the time level and the step ordinal, once every workgroup has logged
+    if (a.e.level && a.e.ord_adv != 0) {
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            if (atomicAdd(a.e.ticket, 1u) == gridDim.x - 1) {
+                a.e.level[0] += a.e.delta;
+                a.e.level[1] = (ord - a.e.ord_off) + a.e.ord_adv;
+                *a.e.ticket = 0u;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- host side
+// 0: not applicable; 1: 3 x 3 blocks, pair-compact rows (N <= 81); 2: 2 x 2 blocks, full rows (N <= 42)
+static int mesh_step_variant(const femfct_ctx* ctx, bool have_nm) {
+    if (!ctx->mesh_step || !ctx->structured || !ctx->implicit_cols || ctx->W != 7 || !ctx->mass_is_mesh) return 0;
+    if (ctx->solver != FEMFCT_SOLVER_JACOBI || ctx->N < 5) return 0;
+    if (ctx->N <= 42) return 2;
+    if (ctx->N <= 81 && ctx->pair_rows && !have_nm) return 1;
+    return 0;
+}
+
+bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch, bool have_nm) {
+    return batch >= ctx->mesh_step_min_batch && mesh_step_variant(ctx, have_nm) != 0;
+}
+
+int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_t nshared, VecRef rhs, int64_t rhs_bstride,
+                             VecRef u_n, int64_t u_bstride, double dt, VecRef u_out, int64_t out_bstride, int32_t batch,
+                             int32_t budget, bool fuse_end) {
+    const int variant = mesh_step_variant(ctx, Nm != nullptr);
+    if (!variant) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step outside its regime");
+    MeshStepArgs a{};
+    // small meshes: 2 x 1 blocks on 1024 threads (a sweep there is a latency chain: the shorter the better) unless
+    // FEMFCT_MESH_SHAPE=22 asks for 2 x 2 blocks on 512
+    static const bool shape22 = getenv("FEMFCT_MESH_SHAPE") && atoi(getenv("FEMFCT_MESH_SHAPE")) == 22;
+    const bool shape21 = variant == 2 && !shape22;
+    const int B = variant == 1 ? 3 : 2, By = variant == 1 ? 3 : (shape21 ? 1 : 2);
+    a.n = ctx->n; a.N = ctx->N;
+    a.TX = (ctx->N + B - 1) / B;
+    a.TY = (ctx->N + By - 1) / By;
+    a.nint = (a.TX - 2) * (a.TY - 2);
+    a.nint_pad = (a.nint + WAVE - 1) / WAVE * WAVE;
+    a.h = ctx->h; a.dt = dt;
+    a.A = A; a.Nm = Nm; a.nm_bs = nshared ? 0 : (int64_t)ctx->W * ctx->n;
+    a.rhs = rhs; a.rhs_bs = rhs_bstride; a.u_n = u_n; a.u_bs = u_bstride; a.out = u_out; a.out_bs = out_bstride;
+    a.ml = ctx->d_ml; a.Md = ctx->d_M; a.Dh = ctx->d_D; a.ctl = ctx->d_ctl;
+    a.rel_tol = ctx->rel_tol;
+    // the solve stops by itself: the budget only bounds a diverging iteration
+    a.max_sweeps = std::min(ctx->max_iters, 2 * std::max(budget, 8) + 16);
+    a.dbg_sweeps = 0; a.dbg_cheb = 20;
+    if (const char* e = getenv("FEMFCT_MESH_DBG")) {
+        if (sscanf(e, "%d,%d", &a.dbg_sweeps, &a.dbg_cheb) == 2) a.max_sweeps = std::max(a.max_sweeps, a.dbg_sweeps);
+        else { a.dbg_sweeps = 0; a.dbg_cheb = 20; }
+    }
+    {
+        const double lmin = 0.5, lmax = 2.0, rho = (lmax - lmin) / (lmax + lmin);
+        double w = 0.0;
+        for (int k = 1; k <= 20; ++k) {          // helpers.py:170-179
+            if (k == 2) w = 1.0 / (1.0 - rho * rho / 2.0);
+            else w = 1.0 / (1.0 - (w * rho * rho) / 4.0);
+            a.om[k - 1] = w;
+        }
+    }
+    a.e = EndArgs{};
+    a.trace = nullptr;
+#ifdef FEMFCT_TUNING
+    a.trace = ctx->d_mesh_trace;       // allocated by femfct_ensure_workspace when FEMFCT_MESH_TRACE is set
+#endif
+    if (fuse_end) {
+        a.e.level = ctx->d_level; a.e.delta = ctx->rep_last ? ctx->end_req_delta * ctx->rep_total : 0;
+        a.e.ord_adv = ctx->rep_last ? ctx->rep_total : 0; a.e.ord_off = ctx->ord_bias; a.e.ctl = ctx->d_ctl; a.e.log = ctx->d_log;
+        a.e.kctl = ctx->end_req_krylov ? (const KrylovCtl*)ctx->d_kry_ctl : nullptr; a.e.klog = (KrylovCtl*)ctx->d_klog;
+        a.e.batch = batch; a.e.ticket = ctx->d_ticket;
+    }
+    const int nthreads = a.nint_pad + 2 * a.TX + 2 * (a.TY - 2);
+    femfct_prof_begin(ctx, KC_JACOBI);
+#define MS_LAUNCH(BX_, BY_, NMAX_, NT_, PAIR_, NFIX_, slot)                                                                   \
+    do {                                                                                                                 \
+        constexpr size_t lds = (size_t)(3 * ((NMAX_ + 2) * (NMAX_ + 1) + 1) + 4 * (NT_ / WAVE)) * 8 + 24;                \
+        if (nthreads > NT_) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step: mesh does not fit");        \
+        if (!ctx->mesh_step_attr[slot]) {                                                                                \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_mesh_step<BX_, BY_, NMAX_, NT_, PAIR_, NFIX_>,               \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+            ctx->mesh_step_attr[slot] = true;                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_mesh_step<BX_, BY_, NMAX_, NT_, PAIR_, NFIX_>), dim3(batch), dim3(NT_), lds, ctx->stream, a); \
+    } while (0)
+    if (variant == 1 && ctx->N == 81) MS_LAUNCH(3, 3, 81, 768, true, 81, 0);
+    else if (variant == 1) MS_LAUNCH(3, 3, 81, 768, true, 0, 1);
+    else if (ctx->N == 41 && shape21) MS_LAUNCH(2, 1, 42, 1024, false, 41, 4);
+    else if (shape21) MS_LAUNCH(2, 1, 42, 1024, false, 0, 5);
+    else if (ctx->N == 41) MS_LAUNCH(2, 2, 42, 512, false, 41, 2);
+    else MS_LAUNCH(2, 2, 42, 512, false, 0, 3);
+#undef MS_LAUNCH
+    femfct_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "one-workgroup step launch failed: %s", hipGetErrorString(e));
+    return FEMFCT_OK;
+}
+
+#ifdef FEMFCT_TUNING
+// phase timestamps (100 MHz ticks) of workgroup 0 of the most recent one-workgroup step
+extern "C" int femfct_mesh_trace(femfct_ctx* ctx, unsigned long long* out16) {
+    FEMFCT_ENTER(ctx);
+    if (!ctx->d_mesh_trace) return FEMFCT_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out16, ctx->d_mesh_trace, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return FEMFCT_OK;
+}
+#endif

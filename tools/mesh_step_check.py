@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""A/B of the one-workgroup-per-trajectory step (kernels_mesh.hip, FEMFCT_MESH_STEP) against the tile path:
+agreement of whole trajectories and microseconds per step for B trajectories per launch.
+  python3 tools/mesh_step_check.py [nc=80] [Nt=50] [B list]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+hp = importlib.import_module("fem-fct-pdeco_amd")
+solvers = importlib.import_module("fem-fct-pdeco_amd.solvers")
+
+nc = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+Nt = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+Bs = [int(b) for b in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 8, 64]
+dt = 1e-3 * 80 / nc
+mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
+n = mesh.nodes
+tl = (Nt + 1) * n
+rng = np.random.default_rng(0)
+N = nc + 1
+xs = np.linspace(-1, 1, N)
+X, Y = np.meshgrid(xs, xs)
+u0 = (np.exp(-20 * ((X + 0.3) ** 2 + (Y + 0.2) ** 2)) + ((X - 0.3) ** 2 + (Y - 0.3) ** 2 < 0.09)).reshape(-1)
+
+
+def run(mesh_step, B, reps=3, adjoint=True):
+    os.environ["FEMFCT_MESH_STEP"] = "1" if mesh_step else "0"
+    prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=B, order=hp.ORDER_VERTEX)
+    ctx = prob.ctx
+    r2 = np.random.default_rng(1)
+    if os.environ.get("CHECK_CONTROL", "smooth") == "random":      # 2 % of the rows with both entries of a pair
+        cks = (2.0 * r2.random((B, 1, n)) * np.ones((B, Nt + 1, 1))).reshape(B, tl)
+    else:                                                         # a PGD iterate looks like this
+        amp = 0.5 + r2.random((B, 1, 1))
+        cks = (amp * (1.0 + 0.5 * np.sin(np.pi * X.reshape(1, 1, n)) * np.cos(np.pi * Y.reshape(1, 1, n))) * np.ones((B, Nt + 1, 1))).reshape(B, tl)
+    init = np.zeros((B, tl)); init[:, :n] = u0
+    c = ctx.array(cks.reshape(-1)); u = ctx.array(init.reshape(-1))
+    uhat = ctx.array(np.tile(u0, B)); p = ctx.zeros(B * tl)
+    for _ in range(2):
+        prob.forward(c, u, batch=B)
+        if adjoint:
+            prob.adjoint(c, u, uhat, p, "finaltime", batch=B)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        prob.forward(c, u, batch=B)
+        if adjoint:
+            prob.adjoint(c, u, uhat, p, "finaltime", batch=B)
+    ctx.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    log = prob.solver_log(batch=B)
+    out = (u.download().reshape(B, tl), p.download().reshape(B, tl))
+    iters = log["solver_iters"].ravel()
+    flags = int(np.bitwise_or.reduce(log["flags"].ravel()))
+    if mesh_step and os.environ.get("FEMFCT_MESH_TRACE"):
+        import ctypes as C
+        buf = (C.c_ulonglong * 16)()
+        if hp._lib.lib.femfct_mesh_trace(ctx.handle, buf) == 0:
+            ts = [buf[i] for i in range(10)]
+            names = ["zero+loads", "pairs", "scale+pool", "jacobi", "dudt", "cheb", "fluxes", "R", "limit"]
+            print("   trace (us): " + " ".join(f"{names[i]} {(ts[i + 1] - ts[i]) / 100:.1f}" for i in range(9)), f"total {(ts[9] - ts[0]) / 100:.1f}  clock {(buf[11] - buf[10]) / max((ts[9] - ts[0]) / 100, 1e-9):.0f} MHz")
+    prob.close()
+    return out, t, (int(min(iters)), int(max(iters))), flags
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+for B in Bs:
+    (u1, p1), t1, it1, f1 = run(True, B)
+    (u0_, p0_), t0_, it0, f0 = run(False, B)
+    steps = 2 * Nt
+    print(f"N={N} B={B:3d}  mesh: {t1 / steps * 1e6:7.1f} us/step ({B * steps / t1:9.0f} timesteps/s) iters {it1} flags {f1:#x} | "
+          f"tiles: {t0_ / steps * 1e6:7.1f} us/step ({B * steps / t0_:9.0f}/s) iters {it0} flags {f0:#x} | "
+          f"rel diff u {rel(u1, u0_):.2e} p {rel(p1, p0_):.2e}  finite {np.isfinite(u1).all()}", flush=True)
