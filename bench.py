@@ -89,15 +89,11 @@ ONE_SWEEP_BYTES = {"jacobi": 80, "cheb": 88, "flux": 184 + 88}
 
 
 def source_sha16():
-    """Identity of the kernel sources a libfemfct.so is built from (profiles/traffic.json carries it)."""
-    h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "fem-fct-pdeco_amd", "csrc", "*.hip")) +
-                   glob.glob(os.path.join(ROOT, "fem-fct-pdeco_amd", "csrc", "*.h")) +
-                   [os.path.join(ROOT, "include", "femfct.h")])
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Identity of the kernel sources THE LOADED libfemfct.so was compiled from: the library reports the hash the Makefile
+    baked into it (femfct_build_id), so a stale binary beside newer sources cannot pass for the current one.
+    profiles/traffic.json carries the same value."""
+    hp = importlib.import_module("fem-fct-pdeco_amd")
+    return hp._lib.lib.femfct_build_id().decode()
 
 
 def slotted_disc_ic(a1, a2, deltax, slit=0.05):
@@ -230,6 +226,175 @@ class StubProblem:
         pass
 
 
+
+# ---------------------------------------------------------------------------------------------
+# configs 3 and 4 (BASELINE.json configs[2], configs[3]): Schnakenberg and chemotaxis systems on the
+# UnitSquare 41 x 41 mesh, dt = 5e-4, 200 forward + 200 adjoint FCT steps, device-resident sweeps
+#   helpers.py:511-698 (solve_schnak_system / solve_adjoint_schnak_system), :1250-1581 (chemotaxis)
+# ---------------------------------------------------------------------------------------------
+def bench_systems(hp, batches=(1, 20), oracle=True, reps=3):
+    """Per system: forward + adjoint timesteps/s with everything resident in HBM; `parity` of that very run against the
+    CPU oracle on the same inputs (relative l2, tolerance 1e-6); the oracle's own 1-core rate on those inputs as
+    `cpu_baseline`; the same sweeps with B trajectories per launch (the Armijo trials of helpers.py:1583-1713)."""
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 200, 5e-4
+    tl = (Nt + 1) * n
+    S = systems._system(V)
+    ctx, v2d = S.ctx, S.v2d
+    rng = np.random.default_rng(31)
+    out = {}
+
+    def to_dev(x):          # FEniCS DoF order (what the reference's arrays are in) -> the device's vertex order
+        return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, n)[:, v2d]).ravel()
+
+    def from_dev(x):
+        o = np.empty((x.size // n, n))
+        o[:, v2d] = x.reshape(-1, n)
+        return o.ravel()
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+    def traj0(x0, B=1):
+        a = np.zeros((B, tl))
+        a[:, :n] = to_dev(x0)
+        return ctx.array(a.ravel())
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    par_s, wind = systems._schnak_par()
+    Aw, AwT = S.convection(wind, "schnak")
+    par_c = systems._chtxs_par()
+    u0s, v0s = hp.schnak_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+    u0c, v0c = hp.chtxs_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+    ctrl_s = 0.1 + 0.05 * rng.random(tl)           # (the forward solvers use level 1 of it for every step: SURVEY 8a quirk 1)
+    ctrl_c = 20 * rng.random(tl)
+    for name in ("schnakenberg", "chemotaxis"):
+        sch = name == "schnakenberg"
+        u0, v0, ctrl = (u0s, v0s, ctrl_s) if sch else (u0c, v0c, ctrl_c)
+        entry = {"config": ("C3 Schnak_FCT_PDECO (helpers.py:511-698): UnitSquare 41x41 P1 (n=1681), dt=5e-4, 200 fwd + 200 adj steps, "
+                            "final-time adjoint" if sch else
+                            "C4 chemotaxis_FCT_PDECO_AT (helpers.py:1250-1581): UnitSquare 41x41 P1 (n=1681), dt=5e-4, 200 fwd + 200 adj "
+                            "steps, all-time adjoint, rescaling 1/10"),
+                 "unit": "timesteps/s", "batched": []}
+        for B in batches:
+            u, v, p, q = traj0(u0, B), traj0(v0, B), ctx.zeros(B * tl), ctx.zeros(B * tl)
+            c1 = ctx.array(np.tile(to_dev(ctrl[n:2 * n]), B))
+            if sch:
+                uhT, vhT = ctx.array(np.tile(to_dev(0.9 * u0), B)), ctx.array(np.tile(to_dev(1.1 * v0), B))
+                fwd = lambda: ctx.schnak_forward(Aw, c1, u, v, Nt, dt, par_s, 1.0, batch=B)
+                adj = lambda: ctx.schnak_adjoint(AwT, u, v, uhT, vhT, p, q, Nt, dt, par_s, batch=B)
+            else:
+                call = ctx.array(np.tile(to_dev(ctrl), B))
+                uh, vh = ctx.array(np.tile(to_dev(np.tile(0.9 * u0 + 0.01, Nt + 1)), B)), ctx.array(np.tile(to_dev(np.tile(1.05 * v0, Nt + 1)), B))
+                fwd = lambda: ctx.chtxs_forward(c1, u, v, Nt, dt, par_c, 0.1, batch=B)
+                adj = lambda: ctx.chtxs_adjoint(u, v, uh, vh, p, q, call, Nt, dt, par_c, 0.1, True, batch=B)
+            tf = timed(fwd)
+            ta = timed(adj)
+            val = 2 * Nt * B / (tf + ta)
+            if B == 1:
+                kin = ctx.traj_krylov_info(Nt)
+                entry.update({"value": val, "forward_steps_per_s": Nt / tf, "adjoint_steps_per_s": Nt / ta,
+                              "kernel_regime": int(ctx.kernel_regime(1)), "graph_replay": bool(ctx.graph_replay_active()),
+                              "species_solve_iters_max": int(kin["solver_iters"].max())})
+                if oracle:
+                    from oracle.mesh import SquareMesh
+                    from oracle.assembly import P1Assembler
+                    from oracle import traj as otraj
+                    asm = P1Assembler(SquareMesh(0.0, 1.0, 40))
+                    ug, vg = from_dev(u.download()), from_dev(v.download())
+                    pg, qg = from_dev(p.download()), from_dev(q.download())
+                    uo, vo = np.zeros(tl), np.zeros(tl)
+                    uo[:n], vo[:n] = u0, v0
+                    z = lambda: np.zeros(tl)
+                    t0 = time.perf_counter()
+                    if sch:
+                        otraj.solve_schnak_system(ctrl, uo, vo, asm, n, Nt, dt)
+                        po, qo = otraj.solve_adjoint_schnak_system(uo, vo, 0.9 * u0, 1.1 * v0, z(), z(), Nt * dt, asm, n, Nt, dt)
+                    else:
+                        otraj.solve_chtxs_system(ctrl, uo, vo, asm, n, Nt, dt)
+                        po, qo = otraj.solve_adjoint_chtxs_system(uo, vo, np.tile(0.9 * u0 + 0.01, Nt + 1), np.tile(1.05 * v0, Nt + 1),
+                                                                  z(), z(), ctrl, Nt * dt, asm, n, Nt, dt, None, "alltime")
+                    t_cpu = time.perf_counter() - t0
+                    errs = {"u_rel_l2": rel(ug, uo), "v_rel_l2": rel(vg, vo), "p_rel_l2": rel(pg, po), "q_rel_l2": rel(qg, qo)}
+                    entry["parity"] = dict(errs, tolerance=1e-6, ok=bool(max(errs.values()) < 1e-6),
+                                           against="oracle/traj.py on the inputs of the timed run (adjoint: of the GPU's own states vs the oracle's own)")
+                    entry["cpu_baseline"] = {"value": 2 * Nt / t_cpu, "unit": "timesteps/s", "cores": 1, "kind": "port",
+                                             "sample": f"the same {Nt} forward + {Nt} adjoint steps, oracle (NumPy/SciPy, SuperLU), 1 process",
+                                             "host_cpus": os.cpu_count()}
+            entry["batched"].append({"batch_per_gpu": B, "value": val, "unit": "timesteps/s", "kernel_regime": int(ctx.kernel_regime(B))})
+            for a in ([u, v, p, q, c1] + ([uhT, vhT] if sch else [call, uh, vh])):
+                a.free()
+        out[name] = entry
+    return out
+
+
+def bench_small_mesh_batches(hp, solvers, device_id, batches=(1, 8, 64, 256), Nt=50):
+    """The 41 x 41 mesh of configs 3 / 4 with the solid-body operator, B trajectories per launch: the one-workgroup-per-
+    trajectory step (kernels_mesh.hip, the default for N <= 42) against the tile path (FEMFCT_MESH_STEP=0) on the same
+    inputs -- forward + final-time adjoint timesteps/s and the largest relative l2 difference between the two paths."""
+    nc = 40
+    mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
+    n, dt = mesh.nodes, 1e-3 * 80 / nc
+    tl = (Nt + 1) * n
+    xs = np.linspace(-1, 1, nc + 1)
+    X, Y = np.meshgrid(xs, xs)
+    u0 = (np.exp(-20 * ((X + 0.3) ** 2 + (Y + 0.2) ** 2)) + ((X - 0.3) ** 2 + (Y - 0.3) ** 2 < 0.09)).reshape(-1)
+    rows, ref = [], {}
+    prev = os.environ.get("FEMFCT_MESH_STEP")
+    try:
+        for path in ("mesh", "tiles"):
+            os.environ["FEMFCT_MESH_STEP"] = "1" if path == "mesh" else "0"
+            for B in batches:
+                prob = solvers.SolidBodyDrift(mesh, Nt, dt, batch=B, device_id=device_id, order=hp.ORDER_VERTEX)
+                c = prob.ctx
+                try:
+                    r2 = np.random.default_rng(1)
+                    amp = 0.5 + r2.random((B, 1, 1))
+                    cks = (amp * (1.0 + 0.5 * np.sin(np.pi * X.reshape(1, 1, n)) * np.cos(np.pi * Y.reshape(1, 1, n))) * np.ones((B, Nt + 1, 1))).reshape(-1)
+                    init = np.zeros((B, tl)); init[:, :n] = u0
+                    dc, du, dp = c.array(cks), c.array(init.reshape(-1)), c.zeros(B * tl)
+                    duh = c.array(np.tile(u0, B))
+
+                    def sweep():
+                        prob.forward(dc, du, batch=B)
+                        prob.adjoint(dc, du, duh, dp, "finaltime", batch=B)
+
+                    for _ in range(4):          # (budgets and graphs settle)
+                        sweep()
+                    c.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        sweep()
+                    c.synchronize()
+                    el = (time.perf_counter() - t0) / 3
+                    u, p = du.download(), dp.download()
+                    row = {"path": path, "batch_per_gpu": B, "value": 2 * Nt * B / el, "unit": "timesteps/s", "us_per_step": 1e6 * el / (2 * Nt),
+                           "kernel_regime": int(c.kernel_regime(B)), "sweeps_max": int(prob.solver_log(B)["solver_iters"].max())}
+                    if path == "mesh":
+                        ref[B] = (u, p)
+                    else:
+                        row["rel_l2_vs_mesh_path"] = max(float(np.linalg.norm(u - ref[B][0]) / np.linalg.norm(u)),
+                                                         float(np.linalg.norm(p - ref[B][1]) / np.linalg.norm(p)))
+                    rows.append(row)
+                finally:
+                    prob.close()
+    finally:
+        if prev is None:
+            os.environ.pop("FEMFCT_MESH_STEP", None)
+        else:
+            os.environ["FEMFCT_MESH_STEP"] = prev
+    return {"config": f"solid-body operator on the 41x41 mesh of configs 3/4 (n=1681), {Nt} fwd + {Nt} adj steps, smooth controls", "rows": rows}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +407,7 @@ def main():
                     help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~10 s of one core (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
     ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
+    ap.add_argument("--systems", type=int, default=1, help="1: add configs 3 and 4 (Schnakenberg, chemotaxis; 41x41, 200 + 200 steps) as 'systems'")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (rehearses the RCCL "
                          "calls of the N > 1 path on a one-GPU box)")
@@ -449,6 +615,9 @@ def main():
                                       "launch_info": infob, "kernels": ktab})
             for a in (cb, ub, pb, uhb):
                 a.free()
+    if rank == 0 and world == 1 and args.systems:
+        result["systems"] = bench_systems(hp, oracle=args.cpu_sample > 0)
+        result["small_mesh_batches"] = bench_small_mesh_batches(hp, solvers, device_id)
     if rank == 0 and world == 1 and args.pgd_iters > 0 and not c5:
         # the full optimisation loop of configs[1] (finaltime_Garvie.py:164-330), everything in HBM;
         # speculative = all 10 Armijo trial steps as one batch of independent trajectories

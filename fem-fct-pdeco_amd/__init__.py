@@ -10,7 +10,7 @@ there is no CPU fallback.
 """
 from ._lib import (FemFctError, FemFctValueError, NotConverged, LIB_PATH,  # noqa: F401
                    ORDER_VERTEX, ORDER_FENICS, SOLVER_JACOBI, SOLVER_BICGSTAB,
-                   FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV)
+                   FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV, FLAG_ROW_PAIRS)
 from .device import Context, DeviceArray  # noqa: F401
 from .mesh import SquareMeshP1  # noqa: F401
 from .fct_helpers import (  # noqa: F401

@@ -15,11 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEMFCT_LIB") or os.path.join(_HERE, "lib", "libfemfct.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_NOMEM = 0, 1, 2, 3, 4
-FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV = 1, 2, 4, 8
+FLAG_MMATRIX_ROWSUM, FLAG_SOLVER_BUDGET, FLAG_COARSE_ITERS, FLAG_CHEBYSHEV, FLAG_ROW_PAIRS = 1, 2, 4, 8, 16
 ORDER_VERTEX, ORDER_FENICS = 0, 1
 SOLVER_JACOBI, SOLVER_BICGSTAB = 0, 1
-REGIME_ROWS, REGIME_STRIPS, REGIME_TILE32, REGIME_PATCH64 = 0, 1, 2, 3
-ABI_VERSION = 4
+REGIME_ROWS, REGIME_STRIPS, REGIME_TILE32, REGIME_PATCH64, REGIME_MESH = 0, 1, 2, 3, 4
+ABI_VERSION = 5
 
 
 class FemFctError(RuntimeError):
@@ -65,6 +65,7 @@ _ip = C.POINTER(C.c_int32)
 # name -> (restype, argtypes); mirrors include/femfct.h one to one
 SIGNATURES = {
     "femfct_abi_version": (C.c_int, []),
+    "femfct_build_id": (C.c_char_p, []),
     "femfct_create": (C.c_int, [C.POINTER(_p), C.c_int]),
     "femfct_destroy": (C.c_int, [_p]),
     "femfct_last_error": (C.c_char_p, [_p]),

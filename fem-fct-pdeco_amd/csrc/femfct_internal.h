@@ -96,7 +96,7 @@ struct femfct_ctx {
     std::set<int> kind_fullrows;    // sweep kinds that raised FEMFCT_FLAG_ROW_PAIRS: full-row kernels from then on
     // one workgroup = one trajectory (kernels_mesh.hip): the whole step of a small mesh (N <= 42) in one launch
     bool mesh_step = true;          // FEMFCT_MESH_STEP
-    int mesh_step_min_batch = 2;    // FEMFCT_MESH_STEP_BATCH: trajectories per launch from which it replaces the tile path
+    int mesh_step_min_batch = 1;    // FEMFCT_MESH_STEP_BATCH: trajectories per launch from which it replaces the tile path
     bool mesh_step_attr[2] = {false, false};
     unsigned long long* d_mesh_trace = nullptr;   // FEMFCT_TUNING builds only
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
@@ -269,7 +269,7 @@ int femfct_tile4_init(femfct_ctx* ctx);
 bool femfct_tile4_wanted(const femfct_ctx* ctx, int32_t batch);
 int femfct_tile4_tiles(const femfct_ctx* ctx, int H = 8);
 int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch, bool pair);   // 0: one workgroup per patch
-bool femfct_jacobi_pair_wanted(const femfct_ctx* ctx, int H, int32_t batch, bool have_lmask);
+bool femfct_jacobi_pair_wanted(const femfct_ctx* ctx, int H, int32_t batch, bool have_lmask, bool assume_upwind_rows = false);
 int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps);
 bool femfct_single_patch(const femfct_ctx* ctx, int32_t batch);
 // launches and sweeps per launch the low-order solve of femfct_enqueue_step_mat will use for a budget

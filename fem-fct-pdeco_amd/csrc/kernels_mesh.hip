@@ -26,8 +26,8 @@
 // and flux phase) and the limiter reads three neighbours' R+- instead of six.
 //
 // Low-order solve: x <- D^-1 (b - O x) with the rows scaled by 1 / l_ii, Gauss-Seidel inside a thread's block (the
-// in-block neighbours' new values are at hand), Jacobi across blocks; it stops when max_i |x_i' - x_i| max_j l_jj <=
-// tol ||b|| (an upper bound of the residual the tile path tests).
+// in-block neighbours' new values are at hand), Jacobi across blocks; it stops when max_i l_ii |x_i' - x_i| <= tol ||b||
+// (the residual test of the tile path).
 //
 // The same kernel with 3 x 3 blocks and one value per opposing pair of L (the only form 81 x 81 nodes fit one CU's
 // registers in) was built and measured in round 4: 135-150 us per step against 46 (B = 1) / 158 (B = 64) us on the tile
@@ -214,8 +214,8 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     double* Dh = a.Dh + (int64_t)bz * 7 * n;      // (slot 0 is unused: Dh[0] takes the stores of nodes outside the mesh)
 
     // ------------------------------------------------------------------ build: D, L = M_L + dt (A - D + N), b
-    double x[BY][BX], bp[BY][BX], lc[6][BY][BX];
-    double bmax = 0.0, rsmin = INFINITY, ldmax = 0.0;
+    double x[BY][BX], bp[BY][BX], lc[6][BY][BX], ldv[BY][BX];
+    double bmax = 0.0, rsmin = INFINITY;
     {
         double dsum[BY][BX];
         MS_UNROLL for (int r = 0; r < BY; ++r)
@@ -301,18 +301,18 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 const double rinv = frcp(ld);
                 MS_UNROLL for (int q = 0; q < 6; ++q) lc[q][r][c] *= rinv;
                 bp[r][c] = bi * rinv;
-                ldmax = fmax(ldmax, ld);
+                ldv[r][c] = ld;
                 x[r][c] = ui;
                 MS_FENCE();
             }
     }
     {
-        double t3 = 0.0;
-        reduce4<NW>(bmax, rsmin, ldmax, t3, red);      // (rsmin: still the identity; the row sums come with du/dt)
+        double t2 = 0.0, t3 = 0.0;
+        reduce4<NW>(bmax, rsmin, t2, t3, red);      // (rsmin: still the identity; the row sums come with du/dt)
     }
-    // Residual test: |r_i| = l_ii |x_i' - x_i| <= max_j l_jj |x_i' - x_i| -- the per-node diagonal would cost a register
-    // per node in the sweep loop; the bound can only ask for a sweep more, never for one less.
-    const double tolb = a.rel_tol * bmax, tolx = uniform(tolb / ldmax);
+    // Residual test as on the tile path: l_ii |x_i' - x_i| = |b_i - (L x)_i| for a Jacobi update (in-block Gauss-Seidel
+    // updates make it the residual with the block's earlier nodes already renewed), against tol ||b||_inf.
+    const double tolb = uniform(a.rel_tol * bmax);
     MS_STAMP(3);
     int iters = 0, sflags = 0;
     double resid = 0.0;
@@ -382,13 +382,13 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                     acc = fma(-lc[2][r][c], nb(1, 0), acc);
                     acc = fma(-lc[5][r][c], nb(-1, 0), acc);
                     acc = vz(r, c, acc);
-                    rmx = fmax(rmx, fabs(acc - x[r][c]));      // the bound of |r_i| / l_ii this sweep goes by
+                    rmx = fmax(rmx, fabs(acc - x[r][c]) * ldv[r][c]);
                     x[r][c] = acc;
                 }
                 MS_FENCE();
             }
             publish_rim<BX, BY>(x, img_out, dst);
-            const bool viol = rmx > tolx;
+            const bool viol = rmx > tolb;
             if (__any(viol) && (threadIdx.x % WAVE) == 0) flg[k % 3] = 1;
             if (threadIdx.x == 0) flg[(k + 1) % 3] = 0;
             __syncthreads();
@@ -468,7 +468,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         {
             double r0 = rmx, r2 = 0.0, r3 = 0.0;
             reduce4<NW>(r0, rsmin, r2, r3, red);
-            resid = bmax > 0.0 ? r0 * ldmax / bmax : 0.0;     // (an upper bound of ||r|| / ||b||: see the test)
+            resid = bmax > 0.0 ? r0 / bmax : 0.0;
             if (!(rsmin > 0.0)) sflags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
         }
         publish_rim<BX, BY>(x, 2 * IMG, dst);
@@ -684,7 +684,8 @@ __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
 
 // ---------------------------------------------------------------------------------------------------- host side
 static bool mesh_step_fits(const femfct_ctx* ctx) {
-    if (!ctx->mesh_step || !ctx->structured || !ctx->implicit_cols || ctx->W != 7 || !ctx->mass_is_mesh) return false;
+    if (!ctx->mesh_step || !ctx->use_strips || !ctx->use_tiles) return false;      // (femfct_set_fusion(0, 0): one-sweep kernels)
+    if (!ctx->structured || !ctx->implicit_cols || ctx->W != 7 || !ctx->mass_is_mesh) return false;
     return ctx->solver == FEMFCT_SOLVER_JACOBI && ctx->N >= 5 && ctx->N <= 42;
 }
 

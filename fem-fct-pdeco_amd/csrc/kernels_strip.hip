@@ -1833,21 +1833,35 @@ k_strip4_jacobi_walk(int n, int N, const double* __restrict__ L_, const double* 
 // (the zero mask k_build_low publishes says which).  This kernel keeps the non-zero value of each pair plus three select
 // bits: 12 instead of 18 registers per node.  A workgroup of NST waves owns a 64 x (R NST) patch, each thread R vertically
 // adjacent nodes (fewer strips: fewer LDS edge rows and barrier participants per node), sized so that TWO workgroups fit
-// a CU -- 6 waves x 10 rows at <= 168 VGPRs (three waves per SIMD), 75 KB of LDS -- each walking its own run of patches,
-// one's loads under the other's sweeps.  The FMAs run in the family's pair order (STRIP4_ROW_FMAS) with the neighbour
-// selected per lane: bit-identical to k_strip4_jacobi<0>.  Patches advance by T = 64 - 2H columns and TY = R NST - 2H rows.
-// A row with BOTH entries of a pair (eps > 0, or a user operator that is not upwind) cannot be represented: the kernel
-// raises FEMFCT_FLAG_ROW_PAIRS in the step record and the host repeats the sweep with the full-row kernels
-// (femfct_run_sweep); outside the trajectory sweeps the kernel is not used.
+// a CU -- the product shape is 6 rows x 8 waves (512 threads, a 64 x 48 patch) at <= 128 VGPRs (four waves per SIMD) and
+// ~81.5 KB of LDS -- each walking its own run of patches, one's loads under the other's sweeps.  The FMAs run in the
+// family's pair order (STRIP4_ROW_FMAS) with the neighbour selected per lane: bit-identical to k_strip4_jacobi<0>.
+// Patches advance by T = 64 - 2H columns and TY = R NST - 2H rows.
+// Rows with BOTH entries of a pair (where a wind component changes sign) go to a patch-wide pool in LDS (below); only a
+// patch with more of them than the pool holds (a diffusive or otherwise non-upwind operator) raises FEMFCT_FLAG_ROW_PAIRS
+// in the step record, and the host repeats the sweep with the full-row kernels (femfct_run_sweep); outside the
+// trajectory sweeps the kernel is not used.
+// The measurement knobs of round 3 (start-up stagger, phase timestamps, priority scheme, work split between the two
+// workgroups of a CU: all measured neutral) and the other patch shapes exist in the -DFEMFCT_TUNING build only.
 constexpr int PAIR_CARRY_ROWS = 18;       // 2 * H, H <= 9 (the Jacobi launches: 36 sweeps = 4 x 9)
 constexpr int PAIR_POOL = 160;            // nodes of a patch with both entries of some pair (see below): 6 doubles each
+#ifdef FEMFCT_TUNING
+#define PAIR_TUNING_PARAMS , int stagger_ticks, unsigned long long* __restrict__ trace, int prio_mode, int first_half_pct
+#define PAIR_TUNING_ARGS , ctx->pair_stagger, ctx->d_pair_trace, ctx->pair_prio, ctx->pair_split
+#else
+#define PAIR_TUNING_PARAMS
+#define PAIR_TUNING_ARGS
+#endif
 template <int R, int NST>
 __global__ void __launch_bounds__(64 * NST, (2 * NST + 3) / 4)
 k_strip_jacobi_pair_walk(int n, int N, const double* __restrict__ L_, const double* __restrict__ b_, double* __restrict__ xa_,
                          double* __restrict__ xb_, double* __restrict__ part, StepCtl* __restrict__ ctl_, int launch, int K,
                          int g_build, double rel_tol, int H, const uint8_t* __restrict__ lmask, int npy, int npatch,
-                         int up, int64_t zero_index, int stagger_ticks, unsigned long long* __restrict__ trace, int prio_mode,
-                         int first_half_pct) {
+                         int up, int64_t zero_index PAIR_TUNING_PARAMS) {
+#ifndef FEMFCT_TUNING
+    constexpr int stagger_ticks = 0, prio_mode = 0, first_half_pct = 50;
+    constexpr unsigned long long* trace = nullptr;
+#endif
     constexpr int W = 7, PR = R * NST;
     __shared__ double top[2][NST][64], bot[2][NST][64];
     __shared__ double carry[PAIR_CARRY_ROWS][6][64];        // three pair values, diagonal, b, input iterate
@@ -1861,6 +1875,10 @@ k_strip_jacobi_pair_walk(int n, int N, const double* __restrict__ L_, const doub
     __shared__ uint8_t pool_mask[PAIR_POOL];
     __shared__ int pool_cnt;
     __shared__ double smem[32];
+    // two workgroups per CU is the point of this kernel: growing PAIR_POOL or PAIR_CARRY_ROWS must not cost that silently
+    static_assert(2 * (sizeof(top) + sizeof(bot) + sizeof(carry) + sizeof(carry_nz) + sizeof(pool_val) + sizeof(pool_node) +
+                       sizeof(pool_mask) + sizeof(smem) + 64) <= 160 * 1024 || NST != 8,
+                  "k_strip_jacobi_pair_walk: two workgroups no longer fit the LDS of a compute unit");
     const int bz = blockIdx.z;
     StepCtl* ctl = ctl_ + bz;
     if (ctl->done) return;
@@ -2610,15 +2628,18 @@ int femfct_tile4_halo(const femfct_ctx* ctx, int sweeps) {
 // hardware dispatch of one workgroup per patch fills the chip better.
 // pair: the launch is k_strip_jacobi_pair_walk<PAIR_R, PAIR_NST> -- two such workgroups fit a CU, so twice the walkers
 // (but still at least two patches per walker, and the same regime boundary as the 1024-thread walk).
-// shape = rows per thread x waves per workgroup (FEMFCT_PAIR_SHAPE, a measurement knob: 3 = 8 x 8, 4 = 7 x 8, 6 = 12 x 4;
-// anything else = the product's 6 x 8; the 6-wave shapes of DESIGN.md section 8 are not compiled in)
+// shape = rows per thread x waves per workgroup: 6 x 8.  (-DFEMFCT_TUNING builds: FEMFCT_PAIR_SHAPE 3 = 8 x 8, 4 = 7 x 8,
+// 6 = 12 x 4, the shapes DESIGN.md section 8 reports on)
 static void pair_shape(const femfct_ctx* ctx, int* R, int* NST) {
+    *R = 6; *NST = 8;
+#ifdef FEMFCT_TUNING
     switch (ctx->pair_shape) {
         case 6: *R = 12; *NST = 4; break;
         case 3: *R = 8; *NST = 8; break;
         case 4: *R = 7; *NST = 8; break;
-        default: *R = 6; *NST = 8; break;
+        default: break;
     }
+#endif
 }
 static int pair_tiles_y(const femfct_ctx* ctx, int H) {
     int R, NST;
@@ -2637,8 +2658,8 @@ int femfct_tile4_walkers(const femfct_ctx* ctx, int H, int32_t batch, bool pair)
 
 // the pair-compact walking launch applies: asked for by the sweep driver (ctx->pair_rows: a kind of sweep whose rows
 // have so far all been upwind rows), zero masks in use, walking regime
-bool femfct_jacobi_pair_wanted(const femfct_ctx* ctx, int H, int32_t batch, bool have_lmask) {
-    if (!(ctx->t4_pair && ctx->pair_rows && have_lmask && ctx->t4_walk == 1 && 2 * H <= PAIR_CARRY_ROWS && ctx->t4_k == 8)) return false;
+bool femfct_jacobi_pair_wanted(const femfct_ctx* ctx, int H, int32_t batch, bool have_lmask, bool assume_upwind_rows) {
+    if (!(ctx->t4_pair && (ctx->pair_rows || assume_upwind_rows) && have_lmask && ctx->t4_walk == 1 && 2 * H <= PAIR_CARRY_ROWS && ctx->t4_k == 8)) return false;
     if ((uint64_t)ctx->ws_batch * ctx->W * (uint64_t)ctx->n + 1 >= (1ull << 32)) return false;   // 32-bit element offsets into L
     return femfct_tile4_walkers(ctx, H, batch, false) > 0;
 }
@@ -2660,13 +2681,17 @@ int femfct_enqueue_tile4_jacobi(femfct_ctx* ctx, const double* L, const double* 
 #define PAIR_LAUNCH(RR, NN)                                                                                              \
         hipLaunchKernelGGL((k_strip_jacobi_pair_walk<RR, NN>), dim3(walkers, 1, batch), dim3(64 * NN), 0, ctx->stream,    \
                            ctx->n, ctx->N, L, b, xa, xb, ctx->d_part, ctx->d_ctl, launch, K, g_build, ctx->rel_tol, H, lmask, npy, \
-                           t * npy, ctx->t4_snake ? (launch & 1) : 0, (int64_t)ctx->ws_batch * ctx->W * ctx->n, ctx->pair_stagger, ctx->d_pair_trace, ctx->pair_prio, ctx->pair_split)
+                           t * npy, ctx->t4_snake ? (launch & 1) : 0, (int64_t)ctx->ws_batch * ctx->W * ctx->n PAIR_TUNING_ARGS)
+#ifdef FEMFCT_TUNING
         switch (ctx->pair_shape) {
             case 6: PAIR_LAUNCH(12, 4); break;
             case 3: PAIR_LAUNCH(8, 8); break;
             case 4: PAIR_LAUNCH(7, 8); break;
             default: PAIR_LAUNCH(6, 8); break;
         }
+#else
+        PAIR_LAUNCH(6, 8);
+#endif
 #undef PAIR_LAUNCH
     } else if (walkers > 0) {
         hipLaunchKernelGGL(k_strip4_jacobi_walk, dim3(walkers, 1, batch), dim3(STRIP_T), 0, ctx->stream, ctx->n, ctx->N, L, b, xa,

@@ -202,6 +202,8 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
             return FEMFCT_OK;
         });
     };
+    // (a diffusive operator has no upwind rows: no point in finding that out from a whole sweep with the pair-compact launch)
+    if (eps != 0.0) ctx->kind_fullrows.insert(2);
     return femfct_run_sweep(ctx, 2, num_steps, batch, 0, false, begin, step);
 }
 
@@ -264,6 +266,7 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
             return FEMFCT_OK;
         });
     };
+    if (eps != 0.0) ctx->kind_fullrows.insert(3);
     return femfct_run_sweep(ctx, 3, num_steps, batch, num_steps - 1, false, begin, step);
 }
 

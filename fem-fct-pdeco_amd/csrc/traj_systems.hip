@@ -201,6 +201,7 @@ int femfct_nonlinear_forward(femfct_ctx* ctx, const double* Aw_ell, const double
             return femfct_enqueue_step_end(ctx, 1, batch, false);
         });
     };
+    ctx->kind_fullrows.insert(10);      // (diffusion / reaction terms: rows with both entries of a pair from the start)
     return femfct_run_sweep(ctx, 10, num_steps, batch, 0, false, begin, step);
 }
 
@@ -233,6 +234,7 @@ int femfct_nonlinear_adjoint(femfct_ctx* ctx, const double* Aw_ell, const double
             return femfct_enqueue_step_end(ctx, -1, batch, false);
         });
     };
+    ctx->kind_fullrows.insert(11);      // (diffusion / reaction terms: rows with both entries of a pair from the start)
     return femfct_run_sweep(ctx, 11, num_steps, batch, num_steps - 1, false, begin, step);
 }
 
@@ -309,6 +311,7 @@ int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double
             return femfct_enqueue_step_end(ctx, 1, batch, true);
         });
     };
+    ctx->kind_fullrows.insert(12);      // (diffusion / reaction terms: rows with both entries of a pair from the start)
     return femfct_run_sweep(ctx, 12, num_steps, batch, 0, true, begin, step);
 }
 
@@ -400,6 +403,7 @@ int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const doubl
             return femfct_enqueue_step_end(ctx, -1, batch, true);
         });
     };
+    ctx->kind_fullrows.insert(13);      // (diffusion / reaction terms: rows with both entries of a pair from the start)
     return femfct_run_sweep(ctx, 13, num_steps, batch, num_steps - 1, true, begin, step);
 }
 
@@ -443,6 +447,7 @@ int femfct_chtxs_forward(femfct_ctx* ctx, const double* c_level, double* u_traj,
             return femfct_enqueue_step_end(ctx, 1, batch, true);
         });
     };
+    ctx->kind_fullrows.insert(14);      // (diffusion / reaction terms: rows with both entries of a pair from the start)
     return femfct_run_sweep(ctx, 14, num_steps, batch, 0, true, begin, step);
 }
 
@@ -499,6 +504,7 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
             return femfct_enqueue_step_end(ctx, -1, batch, true);
         });
     };
+    ctx->kind_fullrows.insert(15);      // (diffusion / reaction terms: rows with both entries of a pair from the start)
     return femfct_run_sweep(ctx, 15, num_steps, batch, num_steps - 1, true, begin, step);
 }
 

@@ -201,7 +201,9 @@ class SystemPDECO:
         it = fail_count = fail_restart_count = 0
         fail_pass = False
         it_backup = 0
-        hist = dict(cost=[cost_old], armijo_its=[], stop_crit=[])
+        # armijo_margin[it][k]: distance of trial k's Armijo test from its threshold relative to the cost,
+        # (J_trial - J_k + gam/s ||c_inc - c||^2_Q) / |J_k| (> 0: rejected), for the trials the sequential search looks at
+        hist = dict(cost=[cost_old], armijo_its=[], stop_crit=[], armijo_margin=[])
         svals = [P["s0"] / 2 ** k for k in range(K)]
         while (stop_crit >= P["tol"] or fail_pass or it < P["min_iters"]) and it < P["max_iter_GD"]:
             self._descent(c, u, p, q, d)
@@ -214,20 +216,25 @@ class SystemPDECO:
                 J = self._cost(uB, vB, cB, tgB, B)
                 dif = ctx.l2_norm_sq_Q(cB, ckB, Nt, dt, batch=B)
                 acc = K - 1
+                margins = []
                 for k, s in enumerate(svals):
+                    margins.append((float(J[k]) - cost_old + P["gam"] / s * float(dif[k])) / abs(cost_old))
                     if J[k] - cost_old <= -P["gam"] / s * dif[k]:
                         acc = k
                         break
             else:
                 acc = K - 1
+                margins = []
                 for k, s in enumerate(svals):
                     ctx.project_control(c, s, d, P["c_lower"], P["c_upper"], cB, tl)
                     self._state(cB, uB, vB, clev, 1)
                     Jk = float(self._cost(uB, vB, cB, tg)[0])
                     dif = float(ctx.l2_norm_sq_Q(cB, c, Nt, dt)[0])
+                    margins.append((Jk - cost_old + P["gam"] / s * dif) / abs(cost_old))
                     if Jk - cost_old <= -P["gam"] / s * dif:
                         acc = k
                         break
+            hist["armijo_margin"].append(margins)
             slot = acc if speculative else 0
             c.copy_from(cB, tl, src_off=slot * tl)
             u.copy_from(uB, tl, src_off=slot * tl)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FEMFCT_ABI_VERSION 4   /* 4: femfct_patch_walkers; 3: femfct_kernel_regime, femfct_lowop_nonzero_fraction, femfct_chebsi_md, femfct_schnak_*_tw; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
+#define FEMFCT_ABI_VERSION 5   /* 5: femfct_build_id, FEMFCT_REGIME_MESH; 4: femfct_patch_walkers; 3: femfct_kernel_regime, femfct_lowop_nonzero_fraction, femfct_chebsi_md, femfct_schnak_*_tw; 2: femfct_schnak_adjoint(alltime), species solver / PDECO / source-term entry points */
 
 typedef struct femfct_ctx femfct_ctx;
 
@@ -55,11 +55,11 @@ typedef struct femfct_ctx femfct_ctx;
                                          the "3: False" diagnostic of helpers.py:1796-1799 */
 #define FEMFCT_FLAG_SOLVER_BUDGET  2  /* sweep/iteration budget exhausted before tolerance */
 #define FEMFCT_FLAG_COARSE_ITERS   4  /* solver_iters is an upper bound (whole fused launches), not the exact count */
+#define FEMFCT_FLAG_CHEBYSHEV      8  /* species solve done by the Chebyshev iteration; solver_iters is the count that
+                                         meets tolerance/10 at its asymptotic rate (the next sweep's budget) */
 #define FEMFCT_FLAG_ROW_PAIRS      16 /* internal to a trajectory sweep: the pair-compact Jacobi launch met a row with both
                                          entries of an opposing stencil pair; the sweep is repeated with full rows, so
                                          a caller never sees this flag after a successful call */
-#define FEMFCT_FLAG_CHEBYSHEV      8  /* species solve done by the Chebyshev iteration; solver_iters is the count that
-                                         meets tolerance/10 at its asymptotic rate (the next sweep's budget) */
 
 /* DoF numbering of the structured mesh */
 #define FEMFCT_ORDER_VERTEX 0         /* iy*N+ix (dolfin vertex order) */
@@ -79,6 +79,9 @@ typedef struct femfct_step_info {
 
 /* ------------------------------------------------------------------ context */
 int         femfct_abi_version(void);
+/* 16 hex digits: sha256 over the library's source files (names + contents) as they were when THIS binary was compiled.
+ * Measurement records (bench.py, profiles/traffic.json) are stamped with it.  No reference counterpart. */
+const char* femfct_build_id(void);
 int         femfct_create(femfct_ctx** ctx, int device_id);
 int         femfct_destroy(femfct_ctx* ctx);
 const char* femfct_last_error(const femfct_ctx* ctx);
@@ -104,11 +107,15 @@ int         femfct_set_fusion(femfct_ctx* ctx, int strips, int tiles);
 #define FEMFCT_REGIME_STRIPS  1   /* multi-sweep row strips (banded patterns) */
 #define FEMFCT_REGIME_TILE32  2   /* 32 x 32-patch tiles, latency regime (structured mesh, vertex order) */
 #define FEMFCT_REGIME_PATCH64 3   /* 64 x 64-patch register/DPP kernels, bandwidth regime (n * batch >= 90 000) */
+#define FEMFCT_REGIME_MESH    4   /* one workgroup per trajectory, whole step in one launch (structured mesh, vertex order,
+                                     N <= 42 nodes per side, from FEMFCT_MESH_STEP_BATCH trajectories per launch on) */
 int         femfct_kernel_regime(const femfct_ctx* ctx, int32_t batch);
 /* bandwidth regime: persistent workgroups per batch member of the Jacobi / Chebyshev launches for a solve of `sweeps`
  * sweeps (each walks over its share of the 64 x 64 patches; the Jacobi walkers carry the rows two vertically adjacent
  * patches share in LDS); 0 = one workgroup per patch (fewer than two patches per compute unit, other regimes,
- * FEMFCT_T4_WALK=0).  Diagnostic. */
+ * FEMFCT_T4_WALK=0).  This is the count of the 1024-thread walkers; the pair-compact Jacobi launch of an upwind
+ * operator (512-thread walkers, two per compute unit) uses up to twice as many -- femfct_launch_info reports the launch
+ * that actually ran.  Diagnostic. */
 int         femfct_patch_walkers(const femfct_ctx* ctx, int32_t batch, int32_t sweeps);
 /* share of the off-diagonal entries of the most recent low-order operator L = M_L + dt (A - D + N) that are non-zero
  * (an upwind stencil: about one half for pure convection).  In the bandwidth regime the Jacobi launches neither store

@@ -95,7 +95,7 @@ def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, wind
     fail_restart_count = 0
     fail_pass = False
     c_backup, it_backup = ck, 0
-    hist = dict(cost=[cost_fun_old], armijo_its=[], stop_crit=[])
+    hist = dict(cost=[cost_fun_old], armijo_its=[], stop_crit=[], armijo_margin=[])
     while (stop_crit >= P["tol"] or fail_pass or it < P["min_iters"]) and it < P["max_iter_GD"]:
         if problem == "nonlinear":
             dk = -(beta * ck - pk)
@@ -105,7 +105,8 @@ def projected_gradient_descent(problem, asm, M, ic, targets, num_steps, dt, wind
             dk = -(beta * ck - qk * uk / r)
         res = armijo_line_search(uk, ck, dk, targets[0], num_steps, dt, P["c_lower"], P["c_upper"], beta, cost_fun_old,
                                  nodes, optim, M, gam=P["gam"], max_iter=P["max_iter_armijo"], s0=P["s0"],
-                                 nonlinear_solver=state, var2=vk, var2_target=targets[1] if two else None)
+                                 nonlinear_solver=state, var2=vk, var2_target=targets[1] if two else None,
+                                 margins=hist["armijo_margin"].append([]) or hist["armijo_margin"][-1])
         if two:
             uk, vk, ck, iters = res
         else:

@@ -418,13 +418,15 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
             assert np.array_equal(uk, outs[0][0]) and np.array_equal(pk, outs[0][1])
 
 
-@pytest.mark.parametrize("control", ["smooth", "rough", "diffusive"])
+@pytest.mark.parametrize("control", ["smooth", "rough", "wild", "diffusive"])
 def test_pair_compact_jacobi_launch_is_bitwise_the_full_row_launch(hp, solvers, monkeypatch, control):
     """k_strip_jacobi_pair_walk (one value per opposing stencil pair, two workgroups per CU) against the full-row walking
     launch it replaces: same bits, forward + all-time adjoint at 331^2 nodes with the walks forced onto the small mesh.
     smooth control: ~0.1 % of the rows hold both entries of a pair (pool records); rough (random) control: ~2 % do;
-    diffusive (eps > 0): every row does -- the pool overflows, the kernel raises FEMFCT_FLAG_ROW_PAIRS and the sweep is
-    repeated with the full-row kernels (so the answer is theirs by construction, and no flag reaches the caller)."""
+    wild (random, amplitude 20: the drift terms swamp the rotation): so many do that the pool overflows, the kernel
+    raises FEMFCT_FLAG_ROW_PAIRS and the sweep is repeated with the full-row kernels (so the answer is theirs by
+    construction, and no flag reaches the caller); diffusive (eps > 0): every row does and the driver knows it beforehand
+    -- that kind of sweep never tries the pair-compact launch."""
     nc, Nt = 330, 2
     mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
     n = mesh.nodes
@@ -435,6 +437,8 @@ def test_pair_compact_jacobi_launch_is_bitwise_the_full_row_launch(hp, solvers, 
     c = np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), Nt + 1)
     if control == "rough":
         c = 2.0 * rng.random((Nt + 1) * n)
+    if control == "wild":
+        c = 20.0 * rng.random((Nt + 1) * n)
     eps = 1e-3 if control == "diffusive" else 0.0
     monkeypatch.setenv("FEMFCT_T4_WALKERS", "9")
     outs, kernels = [], []
@@ -447,7 +451,7 @@ def test_pair_compact_jacobi_launch_is_bitwise_the_full_row_launch(hp, solvers, 
             prob.solve_state(c, uk)
             kernels.append(prob.ctx.launch_info()["jacobi_kernel"])
             flags = prob.solver_log(1)["flags"]
-            assert not np.any(flags & hp.FLAG_SOLVER_BUDGET) and not np.any(flags & 16)       # 16: FEMFCT_FLAG_ROW_PAIRS (internal)
+            assert not np.any(flags & hp.FLAG_SOLVER_BUDGET) and not np.any(flags & hp.FLAG_ROW_PAIRS)       # (internal to a sweep)
             pk = prob.solve_adjoint(c, uk, 0.9 * uk + 0.01, np.zeros_like(uk), optim="alltime")
             outs.append((uk.copy(), pk.copy()))
         finally:
@@ -458,8 +462,8 @@ def test_pair_compact_jacobi_launch_is_bitwise_the_full_row_launch(hp, solvers, 
         assert kernels[1] == "k_strip4_jacobi_walk"
         if control == "smooth":
             assert kernels[0] == "k_strip_jacobi_pair_walk", kernels
-        elif control == "diffusive":
-            assert kernels[0] == "k_strip4_jacobi_walk", kernels          # fell back for this kind of sweep
+        elif control in ("wild", "diffusive"):
+            assert kernels[0] == "k_strip4_jacobi_walk", kernels          # fell back / never tried for this kind of sweep
         print(f"[fullsize] pair-compact launch, {control} control: kernel {kernels[0]}")
 
 
@@ -557,3 +561,79 @@ def test_mimura_named_grid_129x129_forward(hp, monkeypatch):
         S.close()
     _report("Mimura-named grid 129^2, 300 steps (T = 30)", u=eu, v=ev)
     assert eu < TOL and ev < TOL
+
+
+def test_mimura_named_grid_129x129_alltime_adjoint(hp, monkeypatch):
+    """solve_adjoint_chtxs_system (helpers.py:1387-1581, all-time misfit, control refreshed per step) on config 4's named
+    grid -- [0,16]^2, 129 x 129 nodes, dt = 0.1 -- 60 steps backward from the oracle's own 60-step forward states,
+    against the oracle.  (The adjoint exp-forms' quadrature degree is inferred, SURVEY 8c: oracle and device share that
+    inference; what this pins is the device implementation at the named size.)"""
+    from oracle import traj as otraj
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    monkeypatch.setattr(otraj, "chtxs_params", lambda: dict(delta=2, Dm=0.05, Df=0.05, chi=0.125, gamma=100, eta=0.5))
+    omesh, asm = _oracle(0.0, 16.0, 128)
+    V = hp.SquareMeshP1(0.0, 16.0, 128)
+    n, Nt, dt = V.nodes, 60, 0.1
+    tl = (Nt + 1) * n
+    rng = np.random.default_rng(23)
+    m0 = 1.0 + 0.05 * rng.random(n)
+    z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
+    uo, vo = otraj.solve_chtxs_system(None, z(m0), z(m0 / 2), asm, n, Nt, dt, control_const=1.0, rescaling=1)
+    ctrl = 1.0 + 0.2 * rng.random(tl)
+    uhat, vhat = 0.95 * uo + 0.01 * rng.random(tl), 1.05 * vo
+    zz = lambda: np.zeros(tl)
+    po, qo = otraj.solve_adjoint_chtxs_system(uo, vo, uhat, vhat, zz(), zz(), ctrl, Nt * dt, asm, n, Nt, dt, None, "alltime",
+                                              rescaling=1)
+    S = systems.PDESystems(V, order=hp.ORDER_FENICS)
+    try:
+        ctx = S.ctx
+        p, q = ctx.zeros(tl), ctx.zeros(tl)
+        ctx.chtxs_adjoint(ctx.array(uo), ctx.array(vo), ctx.array(uhat), ctx.array(vhat), p, q, ctx.array(ctrl), Nt, dt,
+                          [2, 0.05, 0.05, 0.125, 0.5], 1.0, True)
+        ep, eq = rel(p.download(), po), rel(q.download(), qo)
+    finally:
+        S.close()
+    _report("Mimura-named grid 129^2, all-time adjoint, 60 steps", p=ep, q=eq)
+    assert ep < TOL and eq < TOL
+    assert max(ep, eq) < 1e-9
+
+
+@pytest.mark.parametrize("problem", ["schnak", "chtxs"])
+def test_c3_c4_pgd_loops_41x41_200_steps_vs_oracle(hp, problem):
+    """The optimisation LOOPS of configs 3 and 4 at their own size (Schnak_FCT_PDECO_refactored.py:160-262,
+    chemotaxis_FCT_PDECO_AT_refactored.py:160-270): UnitSquare 41 x 41, dt = 5e-4, 200 steps, two projected-gradient
+    iterations with up to six Armijo trials each, speculative (trials as one batch) and sequential, against the oracle
+    loop: the same line-search decisions, every Armijo margin reproduced, costs to 1e-9, final control / states / adjoints
+    to 1e-7 -- and the smallest margin far above the agreement of a cost evaluation, so the decisions are not luck."""
+    from oracle import pdeco as opdeco, traj as otraj
+    _, asm = _oracle(0.0, 1.0, 40)
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 200, 5e-4
+    tl = (Nt + 1) * n
+    z = lambda x0: np.concatenate([x0, np.zeros(Nt * n)])
+    if problem == "schnak":
+        u0, v0 = hp.schnak_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+        ut, vt = otraj.solve_schnak_system(np.full(tl, 0.1), z(u0), z(v0), asm, n, Nt, dt)
+        targets = (ut[Nt * n:].copy(), vt[Nt * n:].copy())            # final-time misfit (HEAD driver)
+    else:
+        u0, v0 = hp.chtxs_sys_IC(0, 1, 0.025, n, V.vertex_to_dof)
+        ut, vt = otraj.solve_chtxs_system(np.full(tl, 10.0), z(u0), z(v0), asm, n, Nt, dt)
+        targets = (ut.copy(), vt.copy())                                # all-time misfit
+    opts = dict(max_iter_GD=2, max_iter_armijo=6, tol=0.0)
+    ref = opdeco.projected_gradient_descent(problem, asm, asm.mass(), (u0, v0), targets, Nt, dt, **opts)
+    mref = [m for ms in ref["armijo_margin"] for m in ms]
+    assert len(mref) >= 2
+    for speculative in (True, False):
+        got = hp.projected_gradient_descent(problem, V, (u0, v0), targets, Nt, dt, speculative=speculative, **opts)
+        assert got["it"] == ref["it"] and got["restored"] == ref["restored"]
+        assert got["armijo_its"] == ref["armijo_its"], (got["armijo_its"], ref["armijo_its"])
+        np.testing.assert_allclose(got["cost"], ref["cost"], rtol=1e-9)
+        mgot = [m for ms in got["armijo_margin"] for m in ms]
+        assert len(mgot) == len(mref)
+        np.testing.assert_allclose(mgot, mref, rtol=1e-6, atol=1e-11)
+        errs = {k: rel(got[k], ref[k]) for k in ("c", "u", "v", "p", "q")}
+        _report(f"{problem} PGD loop 41^2 x 200 steps, {'speculative' if speculative else 'sequential'}: armijo_its "
+                f"{got['armijo_its']}, smallest |margin| {min(abs(m) for m in mgot):.2e}", **errs)
+        for k, e in errs.items():
+            assert e < 1e-7, (k, e)
+    assert min(abs(m) for m in mref) > 1e-9          # three orders above the ~1e-13 agreement of a cost evaluation

@@ -70,12 +70,59 @@ def test_sweep_world_size_2_gloo():
     assert sorted(res[0][2] + res[1][2]) == sorted(betas)
 
 
+def _worker_batched(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sweep = importlib.import_module("fem-fct-pdeco_amd.sweep")
+    # (beta x Armijo trial) units: 3 betas x 3 step sizes = 9 units over 2 ranks: shares of 5 and 4
+    units = [(10.0 ** (-k / 2), 1.0 / 2 ** j) for k in range(3) for j in range(3)]
+    calls = []
+
+    def run_batch(mine):                     # ONE call per rank: its units advance as one batch
+        calls.append(list(mine))
+        return [_unit_cost(b) * s for b, s in mine]
+
+    out = sweep.sweep_batched(units, run_batch, dist)
+    q.put((rank, out, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sweep_batched_world_size_2_gloo_ragged_units():
+    """The partition the device solvers want: every rank gets its share of the (beta x trial) units in ONE call (one
+    batch per GPU), ragged count (9 units, 2 ranks), one all-gather, full ordered result on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batched, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    units = [(10.0 ** (-k / 2), 1.0 / 2 ** j) for k in range(3) for j in range(3)]
+    expect = [_unit_cost(b) * s for b, s in units]
+    res.sort()
+    for rank, out, calls in res:
+        assert out == expect
+        assert len(calls) == 1 and calls[0] == units[rank::2]          # one batch per rank, round-robin shares
+    assert len(res[0][2][0]) == 5 and len(res[1][2][0]) == 4
+
+
 def test_sweep_single_process_and_shard():
     sweep = importlib.import_module("fem-fct-pdeco_amd.sweep")
     assert sweep.sweep([1.0, 2.0, 3.0], lambda b: 2 * b) == [2.0, 4.0, 6.0]
     assert sweep.shard(list(range(8)), 3, 8) == [3]
     assert sweep.shard(list(range(5)), 1, 2) == [1, 3]
     assert sweep.sweep([], lambda b: b) == []
+    assert sweep.sweep_batched([1.0, 2.0, 3.0], lambda bs: [2 * b for b in bs]) == [2.0, 4.0, 6.0]
+    assert sweep.sweep_batched([], lambda bs: 1 / 0) == []          # no units: the batch is not run
+    with pytest.raises(ValueError):
+        sweep.sweep_batched([1.0, 2.0], lambda bs: [0.0])
 
 
 def test_bench_multi_rank_control_flow_under_gloo():
