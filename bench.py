@@ -407,6 +407,7 @@ def main():
                     help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~10 s of one core (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
     ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
+    ap.add_argument("--tolerance-table", type=int, default=1, help="1: low-order solve tolerance 1e-13 / 1e-11 / 1e-9: sweeps, large-mesh steps/s, C2 parity")
     ap.add_argument("--systems", type=int, default=1, help="1: add configs 3 and 4 (Schnakenberg, chemotaxis; 41x41, 200 + 200 steps) as 'systems'")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (rehearses the RCCL "
@@ -664,10 +665,28 @@ def main():
         # what the timed region left in HBM: batch member 0's state and adjoint trajectories for the control ck
         gpu_u = from_dev(d_u.download()[:tl])
         gpu_p = from_dev(d_p.download()[:tl])
-        base, par = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample, gpu_u, gpu_p,
-                                 rot_scale=rot_scale, optim=optim)
+        base, par, (uk_o, pk_o, ns_o) = cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, args.cpu_sample, gpu_u, gpu_p,
+                                                     rot_scale=rot_scale, optim=optim)
         result["cpu_baseline"] = base
         result["parity"] = par
+        if args.tolerance_table and args.roofline_cells > 0 and ns_o == Nt and B == 1:
+            relf = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+            def c2_eval(tol):
+                ctx.set_solver(rel_tol=tol)
+                for _ in range(2):
+                    one_step()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                one_step()
+                ctx.synchronize()
+                el = time.perf_counter() - t0
+                lg = prob.solver_log(B)
+                return {"timesteps_per_s": 2 * Nt / el, "sweeps_max": int(lg["solver_iters"].max()),
+                        "u_rel_l2": relf(from_dev(d_u.download()[:tl]), uk_o), "p_rel_l2": relf(from_dev(d_p.download()[:tl]), pk_o)}
+
+            result["tolerance_table"] = tolerance_table(hp, solvers, device_id, args.roofline_cells, args.roofline_steps, c2_eval)
+            ctx.set_solver(rel_tol=1e-13)
     ranks.close()                 # (the ranks' collectives are over: what follows is rank 0's CPU-only leg)
     if rank == 0 and world > 1 and args.cpu_sample > 0 and not args.stub_solver:
         # the sweep's CPU baseline: N concurrent 1-core oracle processes, one per sweep
@@ -929,7 +948,44 @@ def cpu_baseline(a1, a2, n_cells, Nt, dt, om, u0, ck, uhat, sample, gpu_u=None, 
             "reference_profile_variant": {"value": 1.0 / t_lil, "unit": "timesteps/s",
                                           "sample": f"{reps} FCT steps with LIL matrices + Python loops "
                                                     "(the reference's data structures), no assembly"}}
-    return base, parity
+    return base, parity, (uk, pk, ns)
+
+
+def tolerance_table(hp, solvers, device_id, n_cells, steps, c2_eval, tols=(1e-13, 1e-11, 1e-9)):
+    """What the low-order solve's tolerance buys (the default, 1e-13 ||b||, is not changed): for each rel_tol the sweeps
+    per step and FCT steps/s of the roofline mesh, and the parity of C2's 250 + 250-step trajectories against the oracle
+    (c2_eval(rel_tol) -> dict).  The reference solves this system directly (spsolve, helpers.py:1782); the north-star
+    bar on the solution is 1e-6."""
+    rows = []
+    mesh = hp.SquareMeshP1(-1.0, 1.0, n_cells)
+    n = mesh.nodes
+    dt = 1e-3 * (2.0 / n_cells) / 0.025
+    prob = solvers.SolidBodyDrift(mesh, steps, dt, batch=1, device_id=device_id, order=hp.ORDER_VERTEX)
+    ctx = prob.ctx
+    try:
+        x, y = mesh.coordinates()
+        rng = np.random.default_rng(0)
+        init = np.zeros((steps + 1) * n)
+        init[:n] = np.exp(-20 * ((x + 0.3) ** 2 + (y - 0.2) ** 2)) + 0.01 * rng.random(n)
+        d_c, d_u = ctx.array(np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), steps + 1)), ctx.array(init)
+        for tol in tols:
+            ctx.set_solver(rel_tol=tol)
+            for _ in range(3):                       # the sweep budget settles to the tolerance
+                prob.forward(d_c, d_u, batch=1)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                prob.forward(d_c, d_u, batch=1)
+            ctx.synchronize()
+            el = (time.perf_counter() - t0) / 2
+            log = prob.solver_log(1)
+            rows.append({"rel_tol": tol, "large_mesh_steps_per_s": steps / el,
+                         "large_mesh_sweeps_per_step": float(log["solver_iters"].mean()),
+                         "large_mesh_resid_max": float(log["solver_resid"].max()), "c2": c2_eval(tol)})
+    finally:
+        prob.close()
+    return {"workload": f"synthetic {n_cells + 1}x{n_cells + 1} mesh (the roofline mesh) and C2 (81x81, 250 + 250 steps)",
+            "default_rel_tol": 1e-13, "rows": rows}
 
 
 if __name__ == "__main__":

@@ -97,7 +97,8 @@ struct femfct_ctx {
     // one workgroup = one trajectory (kernels_mesh.hip): the whole step of a small mesh (N <= 42) in one launch
     bool mesh_step = true;          // FEMFCT_MESH_STEP
     int mesh_step_min_batch = 1;    // FEMFCT_MESH_STEP_BATCH: trajectories per launch from which it replaces the tile path
-    bool mesh_step_attr[2] = {false, false};
+    int mesh_step_min_batch_large = 96;   // FEMFCT_MESH_STEP_BATCH_LARGE: the same for 43 <= N <= 81 (3 x 3 blocks)
+    bool mesh_step_attr[4] = {false, false, false, false};
     unsigned long long* d_mesh_trace = nullptr;   // FEMFCT_TUNING builds only
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
     int t4_int = 1;             // Chebyshev on the mesh's mass matrix: interior patches by the two-workgroups-per-CU kernel (FEMFCT_T4_INT)

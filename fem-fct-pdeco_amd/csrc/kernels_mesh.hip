@@ -177,7 +177,7 @@ __device__ __forceinline__ void reduce4(double& a, double& b, double& c, double&
 
 template <int BX, int BY, int NMAX, int NT, int NFIX, bool INTERIOR>
 __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* lds, double* red, int* flg, int bx, int by,
-                                               int bz, int ord) {
+                                               bool spare, int bz, int ord) {
     constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;      // doubles per image
     constexpr int NW = NT / WAVE;
     // NFIX: the config mesh (41 nodes per side) gets its own instantiation: every LDS / HBM row offset is then an immediate
@@ -189,8 +189,8 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     bool colok[BX], rowok[BY];
     MS_UNROLL for (int c = 0; c < BX; ++c) colok[c] = INTERIOR || (ix0 + c < N);
     MS_UNROLL for (int r = 0; r < BY; ++r) rowok[r] = INTERIOR || (iy0 + r < N);
-    // Threads beyond the blocks of their kind repeat block (1, 1) resp. (0, 0): the same inputs through the same code give
-    // the same bits, so their (unconditional) stores are harmless duplicates.
+    // Threads beyond the blocks of their kind (`spare`) go through the motions on block (1, 1) resp. (0, 0) -- they have to
+    // meet every barrier -- but store to trash words and stay out of the reductions and the residual flags.
     // ALLV: every node of every block lies in the mesh (N a multiple of the block size)
     constexpr bool ALLV = INTERIOR || (NFIX != 0 && NFIX % BX == 0 && NFIX % BY == 0);
     auto valid = [&](int r, int c) { return ALLV ? true : (rowok[r] && colok[c]); };
@@ -200,7 +200,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     double* const trash = reinterpret_cast<double*>(flg + 4);
     auto dst = [&](int r, int c, int img) -> double* {
         double* p = &rowp[r + 1][img + c];
-        return ALLV ? p : (valid(r, c) ? p : trash);
+        return (ALLV ? !spare : (valid(r, c) && !spare)) ? p : trash;
     };
     // interior nodes: M_L = h^2, m_ii = h^2 / 2, m_ij = h^2 / 12 (six triangles around the node)
     const double hh = a.h * a.h;
@@ -211,11 +211,16 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     const double* rhs = vec_ptr(a.rhs);
     if (rhs) rhs += bz * a.rhs_bs;
     double* out = const_cast<double*>(vec_ptr(a.out)) + bz * a.out_bs;
-    double* Dh = a.Dh + (int64_t)bz * 7 * n;      // (slot 0 is unused: Dh[0] takes the stores of nodes outside the mesh)
+    double* Dh = a.Dh + (int64_t)bz * 7 * n;      // (slot 0 is unused: it takes the stores of spare threads and of nodes outside the mesh)
 
     // ------------------------------------------------------------------ build: D, L = M_L + dt (A - D + N), b
+    // LEAN (3 x 3 blocks, 81 x 81 nodes: three waves per SIMD, 168 registers for nine nodes): only the six scaled
+    // off-diagonals and the iterate stay in registers through the solve; b / l_ii lives in image 2 (idle during the solve),
+    // and the residual test uses max_j l_jj for every node (an upper bound of the residual: it can only ask for a sweep
+    // more).  With 2 x 2 blocks everything fits and the test is the exact one.
+    constexpr bool LEAN = BX * BY > 4;
     double x[BY][BX], bp[BY][BX], lc[6][BY][BX], ldv[BY][BX];
-    double bmax = 0.0, rsmin = INFINITY;
+    double bmax = 0.0, rsmin = INFINITY, ldmax = 0.0;
     {
         double dsum[BY][BX];
         MS_UNROLL for (int r = 0; r < BY; ++r)
@@ -248,7 +253,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                                     : p == 1 ? nb_get<BX, BY, 1, 1>(ao, rowp, 0, r, c)
                                              : nb_get<BX, BY, 0, 1>(ao, rowp, 0, r, c);
                     ds[r][c] = fmax(0.0, fmax(as[r][c], at));            // d_ij = max(0, a_ij, a_ji), once per edge
-                    (Dh + (ALLV || valid(r, c) ? (int64_t)s * n : 0))[gidx(r, c)] = ds[r][c];
+                    (Dh + ((ALLV || valid(r, c)) && !spare ? (int64_t)s * n : 0))[gidx(r, c)] = ds[r][c];
+                    dsum[r][c] += ds[r][c];
+                    lc[p][r][c] = dt * (as[r][c] - ds[r][c]);            // (before the barrier: a_ij and d_ij need not live across it)
                 }
             // ... and back to the other end of the edge, which sees it in the backward slot
             if (p == 0) publish<BX, BY, -1, 0>(ds, IMG, dst);
@@ -260,59 +267,68 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                     const double dbk = p == 0 ? nb_get<BX, BY, -1, 0>(ds, rowp, IMG, r, c)
                                      : p == 1 ? nb_get<BX, BY, -1, -1>(ds, rowp, IMG, r, c)
                                               : nb_get<BX, BY, 0, -1>(ds, rowp, IMG, r, c);
-                    dsum[r][c] += ds[r][c] + dbk;
-                    double lf = dt * (as[r][c] - ds[r][c]), lb = dt * (ao[r][c] - dbk);
+                    dsum[r][c] += dbk;
+                    double lb = dt * (ao[r][c] - dbk);
                     if (Nm) {      // (uniform branch)
                         const double n1 = (Nm + (int64_t)s * n)[gidx(r, c)], n2 = (Nm + (int64_t)o * n)[gidx(r, c)];
-                        lf += vz(r, c, dt * n1);
+                        lc[p][r][c] += vz(r, c, dt * n1);
                         lb += vz(r, c, dt * n2);
                     }
-                    lc[p][r][c] = lf;
                     lc[3 + p][r][c] = lb;
                 }
         }
         MS_STAMP(2);
-        // (all loads of the phase first, then node by node)
-        double a0v[BY][BX], uv[BY][BX], rb[BY][BX], mlv0[BY][BX], nmv[BY][BX];
-        MS_UNROLL for (int r = 0; r < BY; ++r)
+        if (LEAN) {        // (the sums wait in image 2 while the block rows are scaled one at a time)
+            MS_UNROLL for (int r = 0; r < BY; ++r)
+                MS_UNROLL for (int c = 0; c < BX; ++c) *dst(r, c, 2 * IMG) = dsum[r][c];
+        }
+        // (a block row's loads first, then its nodes one by one)
+        MS_UNROLL for (int r = 0; r < BY; ++r) {
+            double a0v[BX], uv[BX], rb[BX], mlv0[BX], nmv[BX], dsv[BX];
             MS_UNROLL for (int c = 0; c < BX; ++c) {
                 const int i = gidx(r, c);
-                a0v[r][c] = Ab[i]; uv[r][c] = un[i];
-                rb[r][c] = 0.0; nmv[r][c] = 0.0; mlv0[r][c] = hh;
-                if (!INTERIOR) mlv0[r][c] = a.ml[i];
+                a0v[c] = Ab[i]; uv[c] = un[i];
+                rb[c] = 0.0; nmv[c] = 0.0; mlv0[c] = hh;
+                if (!INTERIOR) mlv0[c] = a.ml[i];
+                dsv[c] = LEAN ? lds_read(&rowp[r + 1][2 * IMG + c]) : dsum[r][c];
             }
-        if (rhs) {
-            MS_UNROLL for (int r = 0; r < BY; ++r)
-                MS_UNROLL for (int c = 0; c < BX; ++c) rb[r][c] = rhs[gidx(r, c)];
-        }
-        if (Nm) {
-            MS_UNROLL for (int r = 0; r < BY; ++r)
-                MS_UNROLL for (int c = 0; c < BX; ++c) nmv[r][c] = Nm[gidx(r, c)];
-        }
-        MS_FENCE();
-        MS_UNROLL for (int r = 0; r < BY; ++r)
+            if (rhs) {
+                MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = rhs[gidx(r, c)];
+            }
+            if (Nm) {
+                MS_UNROLL for (int c = 0; c < BX; ++c) nmv[c] = Nm[gidx(r, c)];
+            }
+            MS_FENCE();
             MS_UNROLL for (int c = 0; c < BX; ++c) {
                 const bool vv = valid(r, c);
-                const double mli = INTERIOR ? hh : (ALLV ? mlv0[r][c] : zsel(vv, mlv0[r][c] - 1.0) + 1.0);
-                const double a0 = vz(r, c, a0v[r][c]), ui = vz(r, c, uv[r][c]);
-                const double ld = mli + dt * (a0 + dsum[r][c]) + vz(r, c, dt * nmv[r][c]);
-                const double bi = mli * ui + vz(r, c, dt * rb[r][c]);
+                const double mli = INTERIOR ? hh : (ALLV ? mlv0[c] : zsel(vv, mlv0[c] - 1.0) + 1.0);
+                const double a0 = vz(r, c, a0v[c]), ui = vz(r, c, uv[c]);
+                const double ld = mli + dt * (a0 + dsv[c]) + vz(r, c, dt * nmv[c]);
+                const double bi = mli * ui + vz(r, c, dt * rb[c]);
                 bmax = fmax(bmax, fabs(bi));
                 const double rinv = frcp(ld);
                 MS_UNROLL for (int q = 0; q < 6; ++q) lc[q][r][c] *= rinv;
-                bp[r][c] = bi * rinv;
-                ldv[r][c] = ld;
+                if (LEAN) {
+                    *dst(r, c, 2 * IMG) = bi * rinv;       // (same thread, same address as the sum it has just read)
+                    ldmax = fmax(ldmax, ld);
+                } else {
+                    bp[r][c] = bi * rinv;
+                    ldv[r][c] = ld;
+                }
                 x[r][c] = ui;
                 MS_FENCE();
             }
+        }
     }
     {
-        double t2 = 0.0, t3 = 0.0;
-        reduce4<NW>(bmax, rsmin, t2, t3, red);      // (rsmin: still the identity; the row sums come with du/dt)
+        double t3 = 0.0;
+        if (spare) { bmax = 0.0; ldmax = 0.0; }
+        reduce4<NW>(bmax, rsmin, ldmax, t3, red);      // (rsmin: still the identity; the row sums come with du/dt)
     }
     // Residual test as on the tile path: l_ii |x_i' - x_i| = |b_i - (L x)_i| for a Jacobi update (in-block Gauss-Seidel
     // updates make it the residual with the block's earlier nodes already renewed), against tol ||b||_inf.
-    const double tolb = uniform(a.rel_tol * bmax);
+    // LEAN: |x_i' - x_i| against tol ||b|| / max_j l_jj.
+    const double tolb = uniform(LEAN ? a.rel_tol * bmax / ldmax : a.rel_tol * bmax);
     MS_STAMP(3);
     int iters = 0, sflags = 0;
     double resid = 0.0;
@@ -373,7 +389,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 MS_UNROLL for (int u = 0; u < BX; ++u) {
                     const int c = rev ? BX - 1 - u : u;
                     auto nb = [&](int dy, int dx) -> double { return nbv<BX, BY>(x, v, r + dy, c + dx); };
-                    double acc = bp[r][c];
+                    double acc = LEAN ? lds_read(&rowp[r + 1][2 * IMG + c]) : bp[r][c];
                     // (E, W), (NE, SW), (N, S): the accumulation order of the tile kernels
                     acc = fma(-lc[0][r][c], nb(0, 1), acc);
                     acc = fma(-lc[3][r][c], nb(0, -1), acc);
@@ -382,13 +398,13 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                     acc = fma(-lc[2][r][c], nb(1, 0), acc);
                     acc = fma(-lc[5][r][c], nb(-1, 0), acc);
                     acc = vz(r, c, acc);
-                    rmx = fmax(rmx, fabs(acc - x[r][c]) * ldv[r][c]);
+                    rmx = fmax(rmx, LEAN ? fabs(acc - x[r][c]) : fabs(acc - x[r][c]) * ldv[r][c]);
                     x[r][c] = acc;
                 }
                 MS_FENCE();
             }
             publish_rim<BX, BY>(x, img_out, dst);
-            const bool viol = rmx > tolb;
+            const bool viol = !spare && rmx > tolb;
             if (__any(viol) && (threadIdx.x % WAVE) == 0) flg[k % 3] = 1;
             if (threadIdx.x == 0) flg[(k + 1) % 3] = 0;
             __syncthreads();
@@ -466,9 +482,10 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             }
         }
         {
-            double r0 = rmx, r2 = 0.0, r3 = 0.0;
+            double r0 = spare ? 0.0 : rmx, r2 = 0.0, r3 = 0.0;
+            if (spare) rsmin = INFINITY;
             reduce4<NW>(r0, rsmin, r2, r3, red);
-            resid = bmax > 0.0 ? r0 / bmax : 0.0;
+            resid = bmax > 0.0 ? (LEAN ? r0 * ldmax : r0) / bmax : 0.0;      // (LEAN: the bound the test went by)
             if (!(rsmin > 0.0)) sflags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
         }
         publish_rim<BX, BY>(x, 2 * IMG, dst);
@@ -618,7 +635,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 acc -= nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c);
                 acc -= nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c);
                 acc -= nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c);
-                (ALLV || valid(r, c) ? out : Dh)[gidx(r, c)] = fma(rml[r][c], acc, x[r][c]);
+                ((ALLV || valid(r, c)) && !spare ? out : Dh)[gidx(r, c)] = fma(rml[r][c], acc, x[r][c]);
             }
     }
 
@@ -652,20 +669,23 @@ __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
     const int ord = a.e.level ? a.e.level[1] + a.e.ord_off : 0;
     MS_STAMP(0);
     // interior blocks first (whole waves), the boundary ring behind them
-    // (spare threads repeat block (1, 1) of the interior resp. block (0, 0) of the ring)
+    // (spare threads: see mesh_step_body)
     int bx = 1, by = 1;
+    bool spare = true;
     const int TXi = a.TX - 2;
     if (tid < a.nint) {
         by = tid / TXi; bx = tid - by * TXi + 1; by += 1;
+        spare = false;
     } else if (tid >= a.nint_pad) {
         const int kk = tid - a.nint_pad, nb = 2 * a.TX + 2 * (a.TY - 2);
         bx = 0; by = 0;
+        spare = kk >= nb;
         if (kk < a.TX) { bx = kk; }
         else if (kk < 2 * a.TX) { bx = kk - a.TX; by = a.TY - 1; }
         else if (kk < nb) { const int k2 = kk - 2 * a.TX; by = 1 + (k2 >> 1); bx = (k2 & 1) ? a.TX - 1 : 0; }
     }
-    if (tid < a.nint_pad) mesh_step_body<BX, BY, NMAX, NT, NFIX, true>(a, lds, red, flg, bx, by, bz, ord);
-    else mesh_step_body<BX, BY, NMAX, NT, NFIX, false>(a, lds, red, flg, bx, by, bz, ord);
+    if (tid < a.nint_pad) mesh_step_body<BX, BY, NMAX, NT, NFIX, true>(a, lds, red, flg, bx, by, spare, bz, ord);
+    else mesh_step_body<BX, BY, NMAX, NT, NFIX, false>(a, lds, red, flg, bx, by, spare, bz, ord);
     // the graph's last step moves the time level and the step ordinal, once every workgroup has logged
     if (a.e.level && a.e.ord_adv != 0) {
         __syncthreads();
@@ -686,11 +706,14 @@ __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
 static bool mesh_step_fits(const femfct_ctx* ctx) {
     if (!ctx->mesh_step || !ctx->use_strips || !ctx->use_tiles) return false;      // (femfct_set_fusion(0, 0): one-sweep kernels)
     if (!ctx->structured || !ctx->implicit_cols || ctx->W != 7 || !ctx->mass_is_mesh) return false;
-    return ctx->solver == FEMFCT_SOLVER_JACOBI && ctx->N >= 5 && ctx->N <= 42;
+    return ctx->solver == FEMFCT_SOLVER_JACOBI && ctx->N >= 5 && ctx->N <= 81;
 }
 
+// N <= 42: 2 x 2 blocks, from mesh_step_min_batch trajectories per launch on (1: always).  43 <= N <= 81: 3 x 3 blocks,
+// from mesh_step_min_batch_large on -- below that the tile path's four launches, spread over many CUs, are faster.
 bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch) {
-    return batch >= ctx->mesh_step_min_batch && mesh_step_fits(ctx);
+    if (!mesh_step_fits(ctx)) return false;
+    return batch >= (ctx->N <= 42 ? ctx->mesh_step_min_batch : ctx->mesh_step_min_batch_large);
 }
 
 int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_t nshared, VecRef rhs, int64_t rhs_bstride,
@@ -698,7 +721,7 @@ int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_
                              int32_t budget, bool fuse_end) {
     if (!mesh_step_fits(ctx)) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step outside its regime");
     MeshStepArgs a{};
-    constexpr int B = 2;
+    const int B = ctx->N <= 42 ? 2 : 3;
     a.n = ctx->n; a.N = ctx->N;
     a.TX = a.TY = (ctx->N + B - 1) / B;
     a.nint = (a.TX - 2) * (a.TY - 2);
@@ -736,7 +759,7 @@ int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_
     }
     const int nthreads = a.nint_pad + 2 * a.TX + 2 * (a.TY - 2);
     femfct_prof_begin(ctx, KC_JACOBI);
-#define MS_LAUNCH(NMAX_, NT_, NFIX_, slot)                                                                               \
+#define MS_LAUNCH(B, NMAX_, NT_, NFIX_, slot)                                                                            \
     do {                                                                                                                 \
         constexpr size_t lds = (size_t)(3 * ((NMAX_ + 2) * (NMAX_ + 1) + 1) + 4 * (NT_ / WAVE)) * 8 + 24;                \
         if (nthreads > NT_) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step: mesh does not fit");        \
@@ -747,8 +770,10 @@ int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_
         }                                                                                                                \
         hipLaunchKernelGGL((k_mesh_step<B, B, NMAX_, NT_, NFIX_>), dim3(batch), dim3(NT_), lds, ctx->stream, a);         \
     } while (0)
-    if (ctx->N == 41) MS_LAUNCH(42, 512, 41, 0);
-    else MS_LAUNCH(42, 512, 0, 1);
+    if (ctx->N == 41) MS_LAUNCH(2, 42, 512, 41, 0);
+    else if (ctx->N <= 42) MS_LAUNCH(2, 42, 512, 0, 1);
+    else if (ctx->N == 81) MS_LAUNCH(3, 81, 768, 81, 2);
+    else MS_LAUNCH(3, 81, 768, 0, 3);
 #undef MS_LAUNCH
     femfct_prof_end(ctx);
     hipError_t e = hipGetLastError();
