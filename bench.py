@@ -612,7 +612,8 @@ def main():
             result["batched"].append({"batch_per_gpu": Bx, "value": 2 * Nt * Bx / el, "unit": "timesteps/s",
                                       "ms_per_step": 1e3 * el, "kernel_regime": regime_b,
                                       "regime_name": {0: "one-sweep row kernels", 1: "row strips", 2: "32-patch tiles (latency regime)",
-                                                      3: "64-patch register strips (bandwidth regime)"}.get(regime_b, "?"),
+                                                      3: "64-patch register strips (bandwidth regime)",
+                                                     4: "one workgroup per trajectory (whole step in one launch)"}.get(regime_b, "?"),
                                       "launch_info": infob, "kernels": ktab})
             for a in (cb, ub, pb, uhb):
                 a.free()
@@ -970,14 +971,15 @@ def tolerance_table(hp, solvers, device_id, n_cells, steps, c2_eval, tols=(1e-13
         d_c, d_u = ctx.array(np.tile(1.0 + 0.5 * np.sin(3 * x) * np.cos(2 * y), steps + 1)), ctx.array(init)
         for tol in tols:
             ctx.set_solver(rel_tol=tol)
-            for _ in range(3):                       # the sweep budget settles to the tolerance
-                prob.forward(d_c, d_u, batch=1)
+            for _ in range(4):                       # the sweep budget settles to the tolerance (a changed budget is a
+                prob.forward(d_c, d_u, batch=1)      # new graph: ~0.1 s of capture, not part of a step)
             ctx.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2):
+            el = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
                 prob.forward(d_c, d_u, batch=1)
-            ctx.synchronize()
-            el = (time.perf_counter() - t0) / 2
+                ctx.synchronize()
+                el = min(el, time.perf_counter() - t0)
             log = prob.solver_log(1)
             rows.append({"rel_tol": tol, "large_mesh_steps_per_s": steps / el,
                          "large_mesh_sweeps_per_step": float(log["solver_iters"].mean()),
@@ -985,7 +987,9 @@ def tolerance_table(hp, solvers, device_id, n_cells, steps, c2_eval, tols=(1e-13
     finally:
         prob.close()
     return {"workload": f"synthetic {n_cells + 1}x{n_cells + 1} mesh (the roofline mesh) and C2 (81x81, 250 + 250 steps)",
-            "default_rel_tol": 1e-13, "rows": rows}
+            "default_rel_tol": 1e-13, "rows": rows,
+            "note": "sweeps are issued in multi-sweep launches (8-12 per launch), so the counts move in those quanta; "
+                    "large-mesh rate = best of 3 forward sweeps after the sweep budget has settled"}
 
 
 if __name__ == "__main__":

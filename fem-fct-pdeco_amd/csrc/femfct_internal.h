@@ -97,8 +97,9 @@ struct femfct_ctx {
     // one workgroup = one trajectory (kernels_mesh.hip): the whole step of a small mesh (N <= 42) in one launch
     bool mesh_step = true;          // FEMFCT_MESH_STEP
     int mesh_step_min_batch = 1;    // FEMFCT_MESH_STEP_BATCH: trajectories per launch from which it replaces the tile path
-    int mesh_step_min_batch_large = 96;   // FEMFCT_MESH_STEP_BATCH_LARGE: the same for 43 <= N <= 81 (3 x 3 blocks)
-    bool mesh_step_attr[4] = {false, false, false, false};
+    int mesh_step_min_batch_large = 64;   // FEMFCT_MESH_STEP_BATCH_LARGE: the same for N = 81 (3 x 3 blocks)
+    bool mesh_step_attr[6] = {false, false, false, false, false, false};
+    double* d_zero = nullptr;             // n zeros: the 'no rhs' vector of the one-workgroup step
     unsigned long long* d_mesh_trace = nullptr;   // FEMFCT_TUNING builds only
     int defer_check = 1;        // two-launch tile solves: residual test reconstructed after the solve (FEMFCT_DEFER_CHECK)
     int t4_int = 1;             // Chebyshev on the mesh's mass matrix: interior patches by the two-workgroups-per-CU kernel (FEMFCT_T4_INT)
@@ -283,7 +284,7 @@ int femfct_enqueue_tile4_cheb(femfct_ctx* ctx, const double* b, const double* in
                               double* bufB0, double* bufB1, int32_t batch,
                               const struct ChebIO* io = nullptr);
 // one workgroup per trajectory (kernels_mesh.hip)
-bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch);
+bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch, bool have_nm = false);
 int femfct_enqueue_mesh_step(femfct_ctx* ctx, struct MatRef A, const double* Nm, int32_t nshared, struct VecRef rhs,
                              int64_t rhs_bstride, struct VecRef u_n, int64_t u_bstride, double dt, struct VecRef u_out,
                              int64_t out_bstride, int32_t batch, int32_t budget, bool fuse_end);

@@ -1,5 +1,5 @@
 // One workgroup = one trajectory: the whole FEM-FCT step of a small mesh (N <= 42 nodes per side: the 41 x 41 meshes of
-// configs 3 and 4) in ONE launch.
+// configs 3 and 4; N = 81: config C2, large batches) in ONE launch.
 //   FCT_alg_ref                 /root/reference/helpers.py:1715-1872
 //   artificial_diffusion_mat    /root/reference/helpers.py:206-242   (build phase)
 //   spsolve(L, b)               /root/reference/helpers.py:1782      (solve phase, stops by itself)
@@ -29,9 +29,12 @@
 // in-block neighbours' new values are at hand), Jacobi across blocks; it stops when max_i l_ii |x_i' - x_i| <= tol ||b||
 // (the residual test of the tile path).
 //
-// The same kernel with 3 x 3 blocks and one value per opposing pair of L (the only form 81 x 81 nodes fit one CU's
-// registers in) was built and measured in round 4: 135-150 us per step against 46 (B = 1) / 158 (B = 64) us on the tile
-// path -- see DESIGN.md section 8 and tools/mesh_pair_experiment.hip; it is not part of the library.
+// 81 x 81 (config C2): the same kernel with 3 x 3 blocks on 27 x 27 = 729 of 768 threads ("LEAN": the scaled right-hand
+// side and 1 / l_ii live in the third LDS image during the solve, the stopping test uses max_j l_jj, the spare rim rows
+// of the build are parked in image 1).  It holds all 54 off-diagonal coefficients of a block in registers and still
+// needs 496 B of scratch per thread; per step it costs 116 us alone and 151 / 234 us for 64 / 256 trajectories (tiles:
+// 46 / 159 / 550), so the host picks it from 64 trajectories per launch on.  A variant with one value per opposing pair
+// of L (half the registers) was slower (135-150 us) -- DESIGN.md section 8, tools/mesh_pair_experiment.hip.
 #include "femfct_internal.h"
 #include "device_utils.h"
 #include "forms.h"
@@ -175,9 +178,9 @@ __device__ __forceinline__ void reduce4(double& a, double& b, double& c, double&
     a = uniform(ra); b = uniform(rb); c = uniform(rc); d = uniform(rd);
 }
 
-template <int BX, int BY, int NMAX, int NT, int NFIX, bool INTERIOR>
+template <int BX, int BY, int NMAX, int NT, int NFIX, bool HASNM, bool INTERIOR>
 __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* lds, double* red, int* flg, int bx, int by,
-                                               bool spare, int bz, int ord) {
+                                               int bz, int ord) {
     constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;      // doubles per image
     constexpr int NW = NT / WAVE;
     // NFIX: the config mesh (41 nodes per side) gets its own instantiation: every LDS / HBM row offset is then an immediate
@@ -189,29 +192,31 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     bool colok[BX], rowok[BY];
     MS_UNROLL for (int c = 0; c < BX; ++c) colok[c] = INTERIOR || (ix0 + c < N);
     MS_UNROLL for (int r = 0; r < BY; ++r) rowok[r] = INTERIOR || (iy0 + r < N);
-    // Threads beyond the blocks of their kind (`spare`) go through the motions on block (1, 1) resp. (0, 0) -- they have to
-    // meet every barrier -- but store to trash words and stay out of the reductions and the residual flags.
+    // Threads beyond the blocks of their kind repeat block (1, 1) resp. (0, 0): the same inputs through the same code give
+    // the same bits, so their (unconditional) stores are harmless duplicates -- as long as no address is read back after
+    // being overwritten with something else (the LEAN parking below keeps to that).
     // ALLV: every node of every block lies in the mesh (N a multiple of the block size)
     constexpr bool ALLV = INTERIOR || (NFIX != 0 && NFIX % BX == 0 && NFIX % BY == 0);
     auto valid = [&](int r, int c) { return ALLV ? true : (rowok[r] && colok[c]); };
     auto vz = [&](int r, int c, double val) { return ALLV ? val : zsel(valid(r, c), val); };      // 0 outside the mesh
-    const int gi0 = iy0 * N + ix0;
+    int gi0 = iy0 * N + ix0;
     auto gidx = [&](int r, int c) { return ALLV ? gi0 + r * N + c : (valid(r, c) ? gi0 + r * N + c : 0); };   // safe to load from
     double* const trash = reinterpret_cast<double*>(flg + 4);
     auto dst = [&](int r, int c, int img) -> double* {
         double* p = &rowp[r + 1][img + c];
-        return (ALLV ? !spare : (valid(r, c) && !spare)) ? p : trash;
+        return ALLV ? p : (valid(r, c) ? p : trash);
     };
     // interior nodes: M_L = h^2, m_ii = h^2 / 2, m_ij = h^2 / 12 (six triangles around the node)
     const double hh = a.h * a.h;
 
     const double* Ab = mat_ptr(a.A, bz);
-    const double* Nm = a.Nm ? a.Nm + bz * a.nm_bs : nullptr;
+    // HASNM: with a non-flux matrix (its own instantiation: a run-time test inside the unrolled node loops would be a
+    // branch per block row, and the values loaded before it are spilled across it)
+    const double* Nm = HASNM ? a.Nm + bz * a.nm_bs : nullptr;
     const double* un = vec_ptr(a.u_n) + bz * a.u_bs;
-    const double* rhs = vec_ptr(a.rhs);
-    if (rhs) rhs += bz * a.rhs_bs;
+    const double* rhs = vec_ptr(a.rhs) + bz * a.rhs_bs;      // (never null: the launcher passes a vector of zeros for 'no rhs')
     double* out = const_cast<double*>(vec_ptr(a.out)) + bz * a.out_bs;
-    double* Dh = a.Dh + (int64_t)bz * 7 * n;      // (slot 0 is unused: it takes the stores of spare threads and of nodes outside the mesh)
+    double* Dh = a.Dh + (int64_t)bz * 7 * n;      // (slot 0 is unused: Dh[0] takes the stores of nodes outside the mesh)
 
     // ------------------------------------------------------------------ build: D, L = M_L + dt (A - D + N), b
     // LEAN (3 x 3 blocks, 81 x 81 nodes: three waves per SIMD, 168 registers for nine nodes): only the six scaled
@@ -221,6 +226,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     constexpr bool LEAN = BX * BY > 4;
     double x[BY][BX], bp[BY][BX], lc[6][BY][BX], ldv[BY][BX];
     double bmax = 0.0, rsmin = INFINITY, ldmax = 0.0;
+    double nrow[BY][BX];          // HASNM: row sums of the non-flux matrix (for the row-sum diagnostic, with du/dt)
+    MS_UNROLL for (int r = 0; r < BY; ++r)
+        MS_UNROLL for (int c = 0; c < BX; ++c) nrow[r][c] = 0.0;
     {
         double dsum[BY][BX];
         MS_UNROLL for (int r = 0; r < BY; ++r)
@@ -253,7 +261,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                                     : p == 1 ? nb_get<BX, BY, 1, 1>(ao, rowp, 0, r, c)
                                              : nb_get<BX, BY, 0, 1>(ao, rowp, 0, r, c);
                     ds[r][c] = fmax(0.0, fmax(as[r][c], at));            // d_ij = max(0, a_ij, a_ji), once per edge
-                    (Dh + ((ALLV || valid(r, c)) && !spare ? (int64_t)s * n : 0))[gidx(r, c)] = ds[r][c];
+                    (Dh + (ALLV || valid(r, c) ? (int64_t)s * n : 0))[gidx(r, c)] = ds[r][c];
                     dsum[r][c] += ds[r][c];
                     lc[p][r][c] = dt * (as[r][c] - ds[r][c]);            // (before the barrier: a_ij and d_ij need not live across it)
                 }
@@ -269,18 +277,21 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                                               : nb_get<BX, BY, 0, -1>(ds, rowp, IMG, r, c);
                     dsum[r][c] += dbk;
                     double lb = dt * (ao[r][c] - dbk);
-                    if (Nm) {      // (uniform branch)
+                    if (HASNM) {
                         const double n1 = (Nm + (int64_t)s * n)[gidx(r, c)], n2 = (Nm + (int64_t)o * n)[gidx(r, c)];
                         lc[p][r][c] += vz(r, c, dt * n1);
                         lb += vz(r, c, dt * n2);
+                        nrow[r][c] += n1 + n2;
                     }
                     lc[3 + p][r][c] = lb;
                 }
         }
         MS_STAMP(2);
-        if (LEAN) {        // (the sums wait in image 2 while the block rows are scaled one at a time)
+        if (LEAN) __syncthreads();      // (image 1 still holds the last pair's d_ij for the neighbours)
+        if (LEAN) {        // (the sums wait in image 1 -- idle until the first sweep -- while the block rows are scaled one at a time;
+                           //  not in image 2, where b / l_ii goes: no address is ever read back after a different value went there)
             MS_UNROLL for (int r = 0; r < BY; ++r)
-                MS_UNROLL for (int c = 0; c < BX; ++c) *dst(r, c, 2 * IMG) = dsum[r][c];
+                MS_UNROLL for (int c = 0; c < BX; ++c) *dst(r, c, IMG) = dsum[r][c];
         }
         // (a block row's loads first, then its nodes one by one)
         MS_UNROLL for (int r = 0; r < BY; ++r) {
@@ -290,12 +301,10 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 a0v[c] = Ab[i]; uv[c] = un[i];
                 rb[c] = 0.0; nmv[c] = 0.0; mlv0[c] = hh;
                 if (!INTERIOR) mlv0[c] = a.ml[i];
-                dsv[c] = LEAN ? lds_read(&rowp[r + 1][2 * IMG + c]) : dsum[r][c];
+                dsv[c] = LEAN ? lds_read(&rowp[r + 1][IMG + c]) : dsum[r][c];
             }
-            if (rhs) {
-                MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = rhs[gidx(r, c)];
-            }
-            if (Nm) {
+            MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = rhs[gidx(r, c)];
+            if (HASNM) {
                 MS_UNROLL for (int c = 0; c < BX; ++c) nmv[c] = Nm[gidx(r, c)];
             }
             MS_FENCE();
@@ -304,12 +313,13 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 const double mli = INTERIOR ? hh : (ALLV ? mlv0[c] : zsel(vv, mlv0[c] - 1.0) + 1.0);
                 const double a0 = vz(r, c, a0v[c]), ui = vz(r, c, uv[c]);
                 const double ld = mli + dt * (a0 + dsv[c]) + vz(r, c, dt * nmv[c]);
+                if (HASNM) nrow[r][c] += nmv[c];
                 const double bi = mli * ui + vz(r, c, dt * rb[c]);
                 bmax = fmax(bmax, fabs(bi));
                 const double rinv = frcp(ld);
                 MS_UNROLL for (int q = 0; q < 6; ++q) lc[q][r][c] *= rinv;
                 if (LEAN) {
-                    *dst(r, c, 2 * IMG) = bi * rinv;       // (same thread, same address as the sum it has just read)
+                    *dst(r, c, 2 * IMG) = bi * rinv;
                     ldmax = fmax(ldmax, ld);
                 } else {
                     bp[r][c] = bi * rinv;
@@ -322,7 +332,6 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     }
     {
         double t3 = 0.0;
-        if (spare) { bmax = 0.0; ldmax = 0.0; }
         reduce4<NW>(bmax, rsmin, ldmax, t3, red);      // (rsmin: still the identity; the row sums come with du/dt)
     }
     // Residual test as on the tile path: l_ii |x_i' - x_i| = |b_i - (L x)_i| for a Jacobi update (in-block Gauss-Seidel
@@ -386,10 +395,12 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             MS_UNROLL for (int t = 0; t < BY; ++t) {
                 const int r = rev ? BY - 1 - t : t;
                 if (t > 0) stage(img_in, r, revtag);
+                double bpv[BX];            // LEAN: the row's b / l_ii, requested with its halo values
+                MS_UNROLL for (int c = 0; c < BX; ++c) bpv[c] = LEAN ? lds_read(&rowp[r + 1][2 * IMG + c]) : bp[r][c];
                 MS_UNROLL for (int u = 0; u < BX; ++u) {
                     const int c = rev ? BX - 1 - u : u;
                     auto nb = [&](int dy, int dx) -> double { return nbv<BX, BY>(x, v, r + dy, c + dx); };
-                    double acc = LEAN ? lds_read(&rowp[r + 1][2 * IMG + c]) : bp[r][c];
+                    double acc = bpv[c];
                     // (E, W), (NE, SW), (N, S): the accumulation order of the tile kernels
                     acc = fma(-lc[0][r][c], nb(0, 1), acc);
                     acc = fma(-lc[3][r][c], nb(0, -1), acc);
@@ -404,7 +415,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 MS_FENCE();
             }
             publish_rim<BX, BY>(x, img_out, dst);
-            const bool viol = !spare && rmx > tolb;
+            const bool viol = rmx > tolb;
             if (__any(viol) && (threadIdx.x % WAVE) == 0) flg[k % 3] = 1;
             if (threadIdx.x == 0) flg[(k + 1) % 3] = 0;
             __syncthreads();
@@ -419,19 +430,23 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             if (st) { cur = 1; break; }
             ++k;
         }
-        gather_halo<BX, BY>(v, rowp, cur ? IMG : 0);       // (the halo of the solution, for du/dt)
         iters = k;
+        // (the node index goes through an opaque move: the HBM addresses of the phases below are then formed here, not
+        //  ahead of the sweep loop, where they would sit in a dozen registers the sweeps need)
+        asm volatile("" : "+v"(gi0));
         MS_STAMP(4);
         if (st != 1) sflags |= FEMFCT_FLAG_SOLVER_BUDGET;
 
         // -------------------------------------------------------------- du/dt: r = rhs - A u_L, then ChebSI on M
-        // (x = u_L with its halo in v; u_L's rim is kept in image 2 for the flux phase.)
+        // (x = u_L, its rim in image `cur`: the halo is read row by row as in a sweep; u_L's rim is kept in image 2 for the
+        //  flux phase.)
         double zb[BY][BX], ym[BY][BX], yo[BY][BX];
         double rw[BY][BX];                // boundary ring: 1 / (2.5 ntri) of the node (mass-matrix weights cnt_ij / (2.5 ntri))
         bool ex[BY][BX], ey[BY][BX];      // ... and whether its E / W resp. N / S edges lie on the mesh boundary (cnt = 1)
         {
             MS_UNROLL for (int r = 0; r < BY; ++r) {
                 // one block row at a time: its 7 x BX matrix entries are requested together, then consumed
+                stage(cur ? IMG : 0, r, std::false_type{});
                 double ar[7][BX], rd[BX], mdv[BX], nsum[BX];
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
                     const int i = gidx(r, c);
@@ -439,13 +454,10 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                     rd[c] = 0.0; mdv[c] = 0.5 * hh; nsum[c] = 0.0;
                     if (!INTERIOR) mdv[c] = a.Md[i];
                 }
-                if (Nm) {
-                    MS_UNROLL for (int c = 0; c < BX; ++c)
-                        MS_UNROLL for (int s = 0; s < 7; ++s) nsum[c] += (Nm + (int64_t)s * n)[gidx(r, c)];
+                if (HASNM) {
+                    MS_UNROLL for (int c = 0; c < BX; ++c) nsum[c] = nrow[r][c];
                 }
-                if (rhs) {
-                    MS_UNROLL for (int c = 0; c < BX; ++c) rd[c] = rhs[gidx(r, c)];
-                }
+                MS_UNROLL for (int c = 0; c < BX; ++c) rd[c] = rhs[gidx(r, c)];
                 MS_FENCE();
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
                     double acc = ar[0][c] * x[r][c], asum = ar[0][c];
@@ -482,8 +494,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             }
         }
         {
-            double r0 = spare ? 0.0 : rmx, r2 = 0.0, r3 = 0.0;
-            if (spare) rsmin = INFINITY;
+            double r0 = rmx, r2 = 0.0, r3 = 0.0;
             reduce4<NW>(r0, rsmin, r2, r3, red);
             resid = bmax > 0.0 ? (LEAN ? r0 * ldmax : r0) / bmax : 0.0;      // (LEAN: the bound the test went by)
             if (!(rsmin > 0.0)) sflags |= FEMFCT_FLAG_MMATRIX_ROWSUM;
@@ -635,7 +646,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 acc -= nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c);
                 acc -= nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c);
                 acc -= nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c);
-                ((ALLV || valid(r, c)) && !spare ? out : Dh)[gidx(r, c)] = fma(rml[r][c], acc, x[r][c]);
+                (ALLV || valid(r, c) ? out : Dh)[gidx(r, c)] = fma(rml[r][c], acc, x[r][c]);
             }
     }
 
@@ -658,7 +669,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     }
 }
 
-template <int BX, int BY, int NMAX, int NT, int NFIX>
+template <int BX, int BY, int NMAX, int NT, int NFIX, bool HASNM>
 __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
     extern __shared__ double lds[];
     constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;
@@ -669,23 +680,20 @@ __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
     const int ord = a.e.level ? a.e.level[1] + a.e.ord_off : 0;
     MS_STAMP(0);
     // interior blocks first (whole waves), the boundary ring behind them
-    // (spare threads: see mesh_step_body)
+    // (spare threads repeat block (1, 1) of the interior resp. block (0, 0) of the ring)
     int bx = 1, by = 1;
-    bool spare = true;
     const int TXi = a.TX - 2;
     if (tid < a.nint) {
         by = tid / TXi; bx = tid - by * TXi + 1; by += 1;
-        spare = false;
     } else if (tid >= a.nint_pad) {
         const int kk = tid - a.nint_pad, nb = 2 * a.TX + 2 * (a.TY - 2);
         bx = 0; by = 0;
-        spare = kk >= nb;
         if (kk < a.TX) { bx = kk; }
         else if (kk < 2 * a.TX) { bx = kk - a.TX; by = a.TY - 1; }
         else if (kk < nb) { const int k2 = kk - 2 * a.TX; by = 1 + (k2 >> 1); bx = (k2 & 1) ? a.TX - 1 : 0; }
     }
-    if (tid < a.nint_pad) mesh_step_body<BX, BY, NMAX, NT, NFIX, true>(a, lds, red, flg, bx, by, spare, bz, ord);
-    else mesh_step_body<BX, BY, NMAX, NT, NFIX, false>(a, lds, red, flg, bx, by, spare, bz, ord);
+    if (tid < a.nint_pad) mesh_step_body<BX, BY, NMAX, NT, NFIX, HASNM, true>(a, lds, red, flg, bx, by, bz, ord);
+    else mesh_step_body<BX, BY, NMAX, NT, NFIX, HASNM, false>(a, lds, red, flg, bx, by, bz, ord);
     // the graph's last step moves the time level and the step ordinal, once every workgroup has logged
     if (a.e.level && a.e.ord_adv != 0) {
         __syncthreads();
@@ -703,23 +711,37 @@ __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------- host side
-static bool mesh_step_fits(const femfct_ctx* ctx) {
+static bool mesh_step_fits(const femfct_ctx* ctx, bool have_nm) {
     if (!ctx->mesh_step || !ctx->use_strips || !ctx->use_tiles) return false;      // (femfct_set_fusion(0, 0): one-sweep kernels)
     if (!ctx->structured || !ctx->implicit_cols || ctx->W != 7 || !ctx->mass_is_mesh) return false;
-    return ctx->solver == FEMFCT_SOLVER_JACOBI && ctx->N >= 5 && ctx->N <= 81;
+    if (ctx->solver != FEMFCT_SOLVER_JACOBI || ctx->N < 5) return false;
+    if (ctx->N <= 42) return true;
+    // 3 x 3 blocks: the 81 x 81 meshes of config C2 with N as a compile-time constant, no non-flux matrix.  (The variant
+    // with N at run time needs 820 B of scratch per thread and is 3-4x slower than the tile path at 61 x 61: tuning builds only.)
+#ifdef FEMFCT_TUNING
+    return ctx->N <= 81 && !have_nm;
+#else
+    return ctx->N == 81 && !have_nm;
+#endif
 }
 
-// N <= 42: 2 x 2 blocks, from mesh_step_min_batch trajectories per launch on (1: always).  43 <= N <= 81: 3 x 3 blocks,
-// from mesh_step_min_batch_large on -- below that the tile path's four launches, spread over many CUs, are faster.
-bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch) {
-    if (!mesh_step_fits(ctx)) return false;
+// N <= 42: 2 x 2 blocks, from mesh_step_min_batch trajectories per launch on (1: always).  N = 81: 3 x 3 blocks, from
+// mesh_step_min_batch_large on -- below that the tile path's four launches, spread over many CUs, are faster
+// (r04, us per step of the batch, one-workgroup | tiles: B=1 116 | 46, B=64 151 | 159, B=256 234 | 550).
+bool femfct_mesh_step_wanted(const femfct_ctx* ctx, int32_t batch, bool have_nm) {
+    if (!mesh_step_fits(ctx, have_nm)) return false;
     return batch >= (ctx->N <= 42 ? ctx->mesh_step_min_batch : ctx->mesh_step_min_batch_large);
 }
 
 int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_t nshared, VecRef rhs, int64_t rhs_bstride,
                              VecRef u_n, int64_t u_bstride, double dt, VecRef u_out, int64_t out_bstride, int32_t batch,
                              int32_t budget, bool fuse_end) {
-    if (!mesh_step_fits(ctx)) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step outside its regime");
+    if (!mesh_step_fits(ctx, Nm != nullptr)) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step outside its regime");
+    if (!rhs.base) {          // 'no rhs' = a vector of zeros (a null test in the kernel would be a branch per block row)
+        if (!ctx->d_zero) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step: workspace not set up");
+        rhs = make_ref(ctx->d_zero);
+        rhs_bstride = 0;
+    }
     MeshStepArgs a{};
     const int B = ctx->N <= 42 ? 2 : 3;
     a.n = ctx->n; a.N = ctx->N;
@@ -759,21 +781,27 @@ int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_
     }
     const int nthreads = a.nint_pad + 2 * a.TX + 2 * (a.TY - 2);
     femfct_prof_begin(ctx, KC_JACOBI);
-#define MS_LAUNCH(B, NMAX_, NT_, NFIX_, slot)                                                                            \
+#define MS_LAUNCH(B, NMAX_, NT_, NFIX_, NM_, slot)                                                                       \
     do {                                                                                                                 \
         constexpr size_t lds = (size_t)(3 * ((NMAX_ + 2) * (NMAX_ + 1) + 1) + 4 * (NT_ / WAVE)) * 8 + 24;                \
         if (nthreads > NT_) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step: mesh does not fit");        \
         if (!ctx->mesh_step_attr[slot]) {                                                                                \
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_mesh_step<B, B, NMAX_, NT_, NFIX_>,                          \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_mesh_step<B, B, NMAX_, NT_, NFIX_, NM_>,                          \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
             ctx->mesh_step_attr[slot] = true;                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_mesh_step<B, B, NMAX_, NT_, NFIX_>), dim3(batch), dim3(NT_), lds, ctx->stream, a);         \
+        hipLaunchKernelGGL((k_mesh_step<B, B, NMAX_, NT_, NFIX_, NM_>), dim3(batch), dim3(NT_), lds, ctx->stream, a);         \
     } while (0)
-    if (ctx->N == 41) MS_LAUNCH(2, 42, 512, 41, 0);
-    else if (ctx->N <= 42) MS_LAUNCH(2, 42, 512, 0, 1);
-    else if (ctx->N == 81) MS_LAUNCH(3, 81, 768, 81, 2);
-    else MS_LAUNCH(3, 81, 768, 0, 3);
+    if (ctx->N == 41 && Nm) MS_LAUNCH(2, 42, 512, 41, true, 0);
+    else if (ctx->N == 41) MS_LAUNCH(2, 42, 512, 41, false, 1);
+    else if (ctx->N <= 42 && Nm) MS_LAUNCH(2, 42, 512, 0, true, 2);
+    else if (ctx->N <= 42) MS_LAUNCH(2, 42, 512, 0, false, 3);
+    else if (ctx->N == 81) MS_LAUNCH(3, 81, 768, 81, false, 4);
+#ifdef FEMFCT_TUNING
+    else MS_LAUNCH(3, 81, 768, 0, false, 5);
+#else
+    else return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step: no variant for this mesh");
+#endif
 #undef MS_LAUNCH
     femfct_prof_end(ctx);
     hipError_t e = hipGetLastError();

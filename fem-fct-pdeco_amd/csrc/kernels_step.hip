@@ -663,7 +663,7 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
                            int64_t out_bstride, int32_t batch, int32_t budget) {
     if (sb && (!femfct_inline_ops_wanted(ctx, batch) || N))
         return femfct_fail(ctx, FEMFCT_ERR_INVALID, "inline solid-body operator outside its regime");
-    if (!sb && femfct_mesh_step_wanted(ctx, batch)) {
+    if (!sb && femfct_mesh_step_wanted(ctx, batch, N != nullptr)) {
         // config-sized mesh: the whole step (and its end) in one launch, one workgroup per trajectory
         const bool fuse_end = ctx->end_req_delta != 0 && ctx->d_ticket && ctx->d_level && ctx->d_log && !ctx->prof_on;
         int r = femfct_enqueue_mesh_step(ctx, A, N, nshared, rhs, rhs_bstride, u_n, u_bstride, dt, u_out, out_bstride, batch,

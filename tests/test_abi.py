@@ -24,7 +24,11 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 40
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.femfct_abi_version() == 4
+    hdr = open(os.path.join(ROOT, "include", "femfct.h")).read()
+    assert lib.femfct_abi_version() == int(re.search(r"#define\s+FEMFCT_ABI_VERSION\s+(\d+)", hdr).group(1)) == 5
+    assert lib.femfct_abi_version() == importlib.import_module("fem-fct-pdeco_amd._lib").ABI_VERSION
+    lib.femfct_build_id.restype = ctypes.c_char_p
+    assert re.fullmatch(r"[0-9a-f]{16}", lib.femfct_build_id().decode())
 
 
 def test_python_binding_covers_header():

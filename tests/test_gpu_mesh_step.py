@@ -1,5 +1,5 @@
 """The one-workgroup-per-trajectory step (csrc/kernels_mesh.hip: meshes with N <= 42 nodes per side in vertex order, the
-default there) through the C ABI (-m gpu): against the tile path it replaces (FEMFCT_MESH_STEP=0) on the same inputs,
+default there; 81 x 81 from 64 trajectories per launch on) through the C ABI (-m gpu): against the tile path it replaces (FEMFCT_MESH_STEP=0) on the same inputs,
 against the CPU oracle, and its own invariants (batched == single bitwise, graphs on/off bitwise).  The systems of
 configs 3 / 4 meet the oracle through this kernel in tests/test_gpu_fullsize.py and tests/test_gpu_systems.py."""
 import importlib
@@ -38,8 +38,12 @@ def _inputs(hp, nc, Nt, B, seed):
     return mesh, n, tl, u0, c, src
 
 
-def _run(hp, solvers, monkeypatch, mesh_step, nc, Nt, B, eps, seed=7, graphs=True):
+def _run(hp, solvers, monkeypatch, mesh_step, nc, Nt, B, eps, seed=7, graphs=True, large_from=None):
     monkeypatch.setenv("FEMFCT_MESH_STEP", "1" if mesh_step else "0")
+    if large_from is None:
+        monkeypatch.delenv("FEMFCT_MESH_STEP_BATCH_LARGE", raising=False)
+    else:
+        monkeypatch.setenv("FEMFCT_MESH_STEP_BATCH_LARGE", str(large_from))
     mesh, n, tl, u0, c, src = _inputs(hp, nc, Nt, B, seed)
     dt = 1e-3 * 80 / nc
     prob = solvers.SolidBodyDrift(mesh, Nt, dt, eps=eps, batch=B, order=hp.ORDER_VERTEX)
@@ -79,6 +83,41 @@ def test_mesh_step_matches_the_tile_path(hp, solvers, monkeypatch, nc, eps):
     # the row-sum diagnostic of helpers.py:1796-1809 (sum_j L_ij from A's row sums here, from L's entries there)
     np.testing.assert_allclose(log1["min_rowsum"], log0["min_rowsum"], rtol=1e-9)
     assert np.array_equal(log1["flags"] & hp.FLAG_MMATRIX_ROWSUM, log0["flags"] & hp.FLAG_MMATRIX_ROWSUM)
+
+
+@pytest.mark.parametrize("eps", [0.0, 2e-3])
+def test_mesh_step_81x81_matches_the_tile_path(hp, solvers, monkeypatch, eps):
+    """The 3 x 3-block instantiation for the 81 x 81 meshes of config C2 (the host picks it from 64 trajectories per
+    launch on; forced on here for 3): same comparison as above."""
+    nc, Nt, B = 80, 6, 3
+    r1, u1, p1, log1 = _run(hp, solvers, monkeypatch, True, nc, Nt, B, eps, large_from=1)
+    r0, u0, p0, log0 = _run(hp, solvers, monkeypatch, False, nc, Nt, B, eps)
+    assert r1 == hp._lib.REGIME_MESH and r0 != hp._lib.REGIME_MESH
+    assert np.isfinite(u1).all() and np.isfinite(p1).all()
+    assert rel(u1, u0) < 1e-11 and rel(p1, p0) < 1e-10, (rel(u1, u0), rel(p1, p0))
+    assert not np.any(log1["flags"] & hp.FLAG_SOLVER_BUDGET)
+    assert log1["solver_resid"].max() <= 1e-13
+    np.testing.assert_allclose(log1["min_rowsum"], log0["min_rowsum"], rtol=1e-9)
+
+
+def test_mesh_step_81x81_is_the_default_from_64_trajectories_on(hp, solvers, monkeypatch):
+    """Default selection at 81 x 81: tiles below 64 trajectories per launch, one workgroup per trajectory from 64 on
+    (64 workgroups of 768 threads in one launch) -- against the tile path on the same 64 trajectories."""
+    nc, Nt, B = 80, 4, 64
+    monkeypatch.setenv("FEMFCT_MESH_STEP", "1")
+    monkeypatch.delenv("FEMFCT_MESH_STEP_BATCH_LARGE", raising=False)
+    mesh = hp.SquareMeshP1(-1.0, 1.0, nc)
+    prob = solvers.SolidBodyDrift(mesh, Nt, 1e-3, batch=B, order=hp.ORDER_VERTEX)
+    try:
+        assert prob.ctx.kernel_regime(8) != hp._lib.REGIME_MESH
+        assert prob.ctx.kernel_regime(63) != hp._lib.REGIME_MESH
+        assert prob.ctx.kernel_regime(64) == hp._lib.REGIME_MESH
+    finally:
+        prob.close()
+    _, ub, pb, logb = _run(hp, solvers, monkeypatch, True, nc, Nt, B, 0.0, seed=11)
+    assert np.isfinite(ub).all() and not np.any(logb["flags"] & hp.FLAG_SOLVER_BUDGET)
+    _, ut, pt, _ = _run(hp, solvers, monkeypatch, False, nc, Nt, B, 0.0, seed=11)
+    assert rel(ub, ut) < 1e-11 and rel(pb, pt) < 1e-10, (rel(ub, ut), rel(pb, pt))
 
 
 def test_mesh_step_batched_equals_single_and_graphs_are_neutral(hp, solvers, monkeypatch):
