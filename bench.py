@@ -59,7 +59,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s is ach
 # vertex order: index-free addressing, no column-index bytes; ELL width 7 = diagonal + 6).  Every
 # array a launch reads or writes is counted once, whatever the number of sweeps it performs.
 # ---------------------------------------------------------------------------------------------
-def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False, half_d: bool = False, l_nonzero: float = 1.0):
+def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False, half_d: bool = False, l_nonzero: float = 1.0,
+                         rot_geom: bool = False):
     """l_nonzero: share of L's off-diagonal entries that are non-zero -- in the bandwidth regime the vanishing ones are
     neither stored by k_build_low nor loaded by k_strip4_jacobi (femfct_lowop_nonzero_fraction), so they are no part
     of the bytes a launch needs.  half_d: D stored once per edge (three slots instead of six, no diagonal)."""
@@ -74,6 +75,9 @@ def launch_bytes_per_row(fused: bool, geom_mass: bool, inline_ops: bool = False,
     if inline_ops:                                  # operator derived in the kernels from Arot + the control's 1-ring
         b["build_low"] = 7 * 8 + l_bytes + d_bytes + 8 * 5 + 1   # Arot, L(w), D(w), c, ml, u_n, b(w), x0(w), zero mask(w)
         b["dudt_rhs"] = 7 * 8 + 8 * 6               # Arot, c, u_L, M_diag, r(w), u_L copy(w), y1(w)
+        if rot_geom:                                # rotation operator evaluated from the node positions: Arot not read
+            b["build_low"] -= 7 * 8
+            b["dudt_rhs"] -= 7 * 8
     if fused:
         b["cheb"] = 8 * 4 + (0 if geom_mass else 7 * 8)            # b, y_mid, y_old|y_old(w), y_new(w) [+ M]
         b["flux"] = (3 * 8 if half_d else 6 * 8) + 8 * 4 + (0 if geom_mass else 6 * 8)   # D, u_L, du, ml, u_out(w) [+ M]: F never stored
@@ -600,7 +604,8 @@ def main():
             infob = ctx.launch_info() if regime_b == 3 else None
             bprb = launch_bytes_per_row(fused=regime_b >= 2 and repb["limit"][1] == 0, geom_mass=os.environ.get("FEMFCT_GEOM_MASS", "1") != "0",
                                         inline_ops=repb["assemble"][1] == 0, half_d=regime_b == 3 and os.environ.get("FEMFCT_HALF_D", "1") != "0",
-                                        l_nonzero=ctx.lowop_nonzero_fraction() if regime_b == 3 else 1.0)
+                                        l_nonzero=ctx.lowop_nonzero_fraction() if regime_b == 3 else 1.0,
+                                        rot_geom=ctx.rotation_derived())
             ktab = {}
             for k, (ms, cnt) in repb.items():
                 if cnt:
@@ -831,8 +836,9 @@ def roofline(hp, solvers, n_cells, steps, device_id):
     inline_ops = rep["assemble"][1] == 0           # no stored operator: k_build_low_sb / k_dudt_rhs_sb
     half_d = regime == 3 and os.environ.get("FEMFCT_HALF_D", "1") != "0"
     l_nonzero = ctx.lowop_nonzero_fraction()       # 1.0 unless the zero mask is in force
+    rot_geom = ctx.rotation_derived()              # Arot evaluated from the node positions in those two kernels, not read
     bpr = launch_bytes_per_row(fused=regime >= 2 and fused_flux, geom_mass=geom, inline_ops=inline_ops, half_d=half_d,
-                               l_nonzero=l_nonzero)
+                               l_nonzero=l_nonzero, rot_geom=rot_geom)
     units = {"assemble": steps}
     one_sweep_units = {"jacobi": sweeps, "cheb": 19 * steps, "flux": steps}
     kernels = _kernel_table(rep, bpr, n, units, traffic, one_sweep_units)
@@ -864,7 +870,8 @@ def roofline(hp, solvers, n_cells, steps, device_id):
            "compulsory_bytes_per_launch": dom["compulsory_bytes_per_row_per_launch"] * n,
            "avg_launch_ms": dom["avg_launch_ms"], "kernel_regime": regime, "patch_walkers": linfo.get("jacobi_walkers", walkers),
            "launch_info": linfo, "source_sha16": sha,
-           "operator": "derived inside k_build_low_sb / k_dudt_rhs_sb" if inline_ops else "stored by k_ops_solidbody",
+           "operator": ("derived inside k_build_low_sb / k_dudt_rhs_sb" + (" (rotation part from the node positions, no Arot read)" if rot_geom else ""))
+                       if inline_ops else "stored by k_ops_solidbody",
            "low_order_offdiag_nonzero_fraction": l_nonzero, "d_stored_once_per_edge": half_d,
            "fct_step_ms": step_ms, "fct_steps_per_s": 1e3 / step_ms, "jacobi_sweeps_per_step": sweeps / steps,
            "step": {"compulsory_bytes": step_bytes, "compulsory_GBps": step_bytes / (1e6 * step_ms),

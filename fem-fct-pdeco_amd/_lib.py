@@ -74,6 +74,7 @@ SIGNATURES = {
     "femfct_set_solver": (C.c_int, [_p, C.c_int, _d, C.c_int]),
     "femfct_set_graphs": (C.c_int, [_p, C.c_int]),
     "femfct_graph_replay_active": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "femfct_rotation_derived": (C.c_int, [_p, C.POINTER(C.c_int)]),
     "femfct_launch_info": (C.c_int, [_p, C.POINTER(C.c_int32)]),
     "femfct_set_fusion": (C.c_int, [_p, C.c_int, C.c_int]),
     "femfct_kernel_regime": (C.c_int, [_p, _i]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "femfct_spmv": (C.c_int, [_p, _p, _p, _d, _d, _p, _i]),
     "femfct_mesh_quad_points": (C.c_int, [_p, _p, _p]),
     "femfct_assemble_convection": (C.c_int, [_p, _p, _d, _p]),
+    "femfct_assemble_rotation": (C.c_int, [_p, _d, _p]),
     "femfct_drift_gradient_rhs": (C.c_int, [_p, _p, _p, _p, _d, _d, _d, _p, _i]),
     "femfct_solidbody_forward": (C.c_int, [_p, _p, _p, _i, _p, _i, _d, _d, _d, _d, _d, _i]),
     "femfct_solidbody_forward_src": (C.c_int, [_p, _p, _p, _i, _p, _p, _i, _d, _d, _d, _d, _d, _i]),

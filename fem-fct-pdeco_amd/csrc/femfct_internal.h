@@ -80,6 +80,11 @@ struct femfct_ctx {
     bool mesh_solve = true;         // species solves of meshes with n <= 4096 as one workgroup per system (FEMFCT_MESH_SOLVE)
     bool mesh_solve_attr[8] = {false, false, false, false, false, false, false, false};
     int single_patch_min_batch = 8; // whole-mesh workgroups (N <= 48) for species solves from this batch size on (FEMFCT_SINGLE_PATCH_BATCH; 0 = off)
+    bool geom_rot = true;       // FEMFCT_GEOM_ROT: bandwidth-regime step kernels derive the rotation operator from (ix, iy)
+    double rot_om = 0.0;        // angular velocity of the last femfct_assemble_rotation
+    bool rot_om_set = false;
+    int* d_rot_check = nullptr;
+    bool last_rot_geom = false; // femfct_rotation_derived
     bool geom_mass = true;      // structured mesh: Chebyshev on M from the cell geometry instead of the stored matrix
     bool t4_dpp = true;         // 64-patch kernels: register-resident strips + DPP lane shifts (else LDS image)
     int t4_k = 8;               // sweeps per 64-patch launch (FEMFCT_T4_K: measurement knob, 1..8)
@@ -262,6 +267,7 @@ int femfct_enqueue_tile_dudt_cheb(femfct_ctx* ctx, struct MatRef A, struct VecRe
                                   int budget_units, int part_count, int iters_per_unit, int exact_k, int iters,
                                   const double* omegas, double md_scale, int32_t batch, int* tail_first = nullptr);
 bool femfct_cheb_flux_fusable(const femfct_ctx* ctx, int32_t batch);
+bool femfct_rotation_is_geometric(femfct_ctx* ctx, const double* Arot, double* om_out);   // kernels_asm.hip
 bool femfct_geom_mass(const femfct_ctx* ctx);   // M may be derived from the cell geometry instead of loaded
 int femfct_enqueue_tile_cheb_flux_limit(femfct_ctx* ctx, const double* b, const double* in_mid, const double* in_old,
                                         int k_first, int k_last, const double* omegas, double md_scale, const double* D,

@@ -67,6 +67,26 @@ __global__ void k_convection_tab(int n, int N, int nc, double h, const int32_t* 
     }
 }
 
+// the same operator for the wind om * (-y, x) in closed form (solidbody_op.h: sb_rot_row); check != null: compare
+// a stored operator with it bit for bit instead (*check |= 1 on the first difference)
+__global__ void k_rotation_op(int n, int N, int nc, double h, double a1, double om, const int32_t* __restrict__ d2v,
+                              double* __restrict__ A, const double* __restrict__ stored, int* __restrict__ check) {
+    RowRange rr = block_rows(n);
+    bool differ = false;
+    for (int i = rr.begin + threadIdx.x; i < rr.end; i += blockDim.x) {
+        NodeXY p = node_xy(i, d2v, N);
+        double rot[STENCIL_W], rotT[STENCIL_W];
+        sb_rot_row<false>(p, nc, h, a1, om, rot, rotT);
+#pragma unroll
+        for (int k = 0; k < STENCIL_W; ++k) {
+            const int64_t idx = (int64_t)k * n + i;
+            if (check) differ |= __double_as_longlong(stored[idx]) != __double_as_longlong(rot[k]);
+            else A[idx] = rot[k];
+        }
+    }
+    if (check && differ) atomicOr(check, 1);
+}
+
 __global__ void k_quad_points(int nc, double a1, double h, double* __restrict__ xq, double* __restrict__ yq) {
     int64_t tri = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t ntri = (int64_t)nc * nc * 2;
@@ -268,6 +288,19 @@ int femfct_assemble_convection(femfct_ctx* ctx, const double* wind_q_host, doubl
     return FEMFCT_OK;
 }
 
+int femfct_assemble_rotation(femfct_ctx* ctx, double om, double* A_ell_dev) {
+    FEMFCT_ENTER(ctx);
+    ARG_TRY(ctx, ctx && ctx->structured, "structured mesh not set");
+    ARG_TRY(ctx, A_ell_dev, "null argument");
+    LaunchGeom g = femfct_geom(ctx, 1);
+    hipLaunchKernelGGL(k_rotation_op, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->N, ctx->n_cells, ctx->h, ctx->a1, om,
+                       ctx->d_d2v, A_ell_dev, (const double*)nullptr, (int*)nullptr);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rot_om = om;          // (a hint for femfct_rotation_is_geometric: the array itself is checked at use)
+    ctx->rot_om_set = true;
+    return FEMFCT_OK;
+}
+
 int femfct_drift_gradient_rhs(femfct_ctx* ctx, const double* c_dev, const double* u_dev, const double* p_dev,
                               double beta, double bx, double by, double* out_dev, int32_t levels) {
     FEMFCT_ENTER(ctx);
@@ -280,3 +313,21 @@ int femfct_drift_gradient_rhs(femfct_ctx* ctx, const double* c_dev, const double
 }
 
 }  // extern "C"
+
+// Is the stored operator Arot, bit for bit, what femfct_assemble_rotation(om) writes for the angular velocity this
+// context last assembled?  Then the bandwidth-regime step kernels derive its rows instead of loading them.  One pass
+// over the array + one 4-byte read-back per trajectory sweep (the sweep itself is >= hundreds of such passes).
+bool femfct_rotation_is_geometric(femfct_ctx* ctx, const double* Arot, double* om_out) {
+    if (!ctx->geom_rot || !ctx->rot_om_set || !ctx->structured || !Arot) return false;
+    if (!ctx->d_rot_check && hipMalloc((void**)&ctx->d_rot_check, sizeof(int)) != hipSuccess) return false;
+    if (hipMemsetAsync(ctx->d_rot_check, 0, sizeof(int), ctx->stream) != hipSuccess) return false;
+    LaunchGeom g = femfct_geom(ctx, 1);
+    hipLaunchKernelGGL(k_rotation_op, g.grid, g.block, 0, ctx->stream, ctx->n, ctx->N, ctx->n_cells, ctx->h, ctx->a1,
+                       ctx->rot_om, ctx->d_d2v, (double*)nullptr, Arot, ctx->d_rot_check);
+    int differ = 1;
+    if (hipMemcpyAsync(&differ, ctx->d_rot_check, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    if (differ) return false;
+    *om_out = ctx->rot_om;
+    return true;
+}

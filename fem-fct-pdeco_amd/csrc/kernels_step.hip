@@ -72,27 +72,40 @@ struct MatOp {
     __device__ __forceinline__ double at(int, int, int j, int ts) const { return A[(int64_t)ts * n + j]; }
 };
 
-template <bool WITH_T>
+// ROTG: the rotation part from the node's lattice position (sb_rot_row) instead of the stored Arot.
+template <bool WITH_T, bool ROTG>
 struct SbOp {
     SbOpArgs p;
     const double* c;
     int n, Nw;
     double h;
-    double acc[STENCIL_W], accT[STENCIL_W];
+    double acc[STENCIL_W], accT[STENCIL_W];      // ROTG: rot_scale * Arot + drift part; else the drift part
     __device__ __forceinline__ void row(int i, unsigned mask) {
         double cv[STENCIL_W];
         cv[0] = c[i];
 #pragma unroll
         for (int s = 1; s < STENCIL_W; ++s) cv[s] = c[col_of<1>(nullptr, n, Nw, mask, s, i)];
         const int iy = i / Nw;
-        sb_drift_row<WITH_T>(NodeXY{i - iy * Nw, iy}, Nw - 1, h, cv, p.bx, p.by, acc, accT);
+        const NodeXY xy{i - iy * Nw, iy};
+        sb_drift_row<WITH_T>(xy, Nw - 1, h, cv, p.bx, p.by, acc, accT);
+        if (ROTG) {
+            double rot[STENCIL_W], rotT[STENCIL_W];
+            sb_rot_row<WITH_T>(xy, Nw - 1, h, p.a1, p.om, rot, rotT);
+#pragma unroll
+            for (int s = 0; s < STENCIL_W; ++s) {
+                acc[s] = p.rot_scale * rot[s] + acc[s];
+                if (WITH_T) accT[s] = p.rot_scale * rotT[s] + accT[s];
+            }
+        }
     }
     __device__ __forceinline__ double a(int s, int i) const {
         const int64_t idx = (int64_t)s * n + i;
+        if (ROTG) return p.eps * (p.eps != 0.0 ? p.Ad[idx] : 0.0) + p.sigma * acc[s];
         return p.eps * (p.eps != 0.0 ? p.Ad[idx] : 0.0) + p.sigma * (p.rot_scale * p.Arot[idx] + acc[s]);
     }
     // a_ji for the neighbour j in slot s (its slot towards i is ts); Ad is symmetric to the bit
     __device__ __forceinline__ double at(int s, int i, int j, int ts) const {
+        if (ROTG) return p.eps * (p.eps != 0.0 ? p.Ad[(int64_t)s * n + i] : 0.0) + p.sigma * accT[s];
         return p.eps * (p.eps != 0.0 ? p.Ad[(int64_t)s * n + i] : 0.0) +
                p.sigma * (p.rot_scale * p.Arot[(int64_t)ts * n + j] + accT[s]);
     }
@@ -229,14 +242,14 @@ __global__ void __launch_bounds__(BS) k_build_low(int n, int Wrt, int Nw, const 
 }
 
 // the same with the solid-body operator derived on the fly (structured mesh, vertex order)
-template <int BS>
+template <int BS, bool ROTG>
 __global__ void __launch_bounds__(BS) k_build_low_sb(int n, int Nw, double h, SbOpArgs sb, VecRef rhs_ref, VecRef u_ref,
                             int64_t rhs_bstride, int64_t u_bstride,
                             const double* __restrict__ ml, double dt, double* __restrict__ L_,
                             double* __restrict__ D_, double* __restrict__ b_, double* __restrict__ x0_,
                             double* __restrict__ part, StepCtl* __restrict__ ctl_,
                             uint8_t* __restrict__ lmask, int half_d) {
-    SbOp<true> op;
+    SbOp<true, ROTG> op;
     op.p = sb; op.c = vec_ptr(sb.c) + blockIdx.y * sb.c_bstride; op.n = n; op.Nw = Nw; op.h = h;
     build_low_body<7, BS, 1>(n, 7, Nw, nullptr, nullptr, op, nullptr, 0, rhs_ref, u_ref, rhs_bstride, u_bstride, ml, dt,
                              L_, D_, b_, x0_, part, ctl_, lmask, half_d);
@@ -364,7 +377,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs(int n, int Wrt, int Nw, const i
                                partk, exact_k);
 }
 
-template <int BS>
+template <int BS, bool ROTG>
 __global__ void __launch_bounds__(BS) k_dudt_rhs_sb(int n, int Nw, double h, SbOpArgs sb,
                            VecRef rhs_ref, int64_t rhs_bstride, const double* __restrict__ M,
                            const double* __restrict__ xa_, const double* __restrict__ xb_,
@@ -372,7 +385,7 @@ __global__ void __launch_bounds__(BS) k_dudt_rhs_sb(int n, int Nw, double h, SbO
                            double* __restrict__ part, StepCtl* __restrict__ ctl_, int budget, int part_count,
                            int iters_per_unit, double rel_tol, double md_scale, double omega1,
                            const double* __restrict__ partk, int exact_k) {
-    SbOp<false> op;
+    SbOp<false, ROTG> op;
     op.p = sb; op.c = vec_ptr(sb.c) + blockIdx.y * sb.c_bstride; op.n = n; op.Nw = Nw; op.h = h;
     dudt_rhs_body<7, BS, 1>(n, 7, Nw, nullptr, op, rhs_ref, rhs_bstride, M, xa_, xb_, ulow_, rdu_, y1_, part, ctl_, budget,
                             part_count, iters_per_unit, rel_tol, md_scale, omega1, partk, exact_k);
@@ -691,8 +704,12 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
     const int half_d = (tile4 && ctx->half_d && ctx->structured && ctx->implicit_cols && W == 7) ? 1 : 0;
     if (sb) {
         femfct_prof_begin(ctx, KC_BUILD_LOW);
-        hipLaunchKernelGGL((k_build_low_sb<256>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, u_n, rhs_bstride,
-                           u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl, lmask, half_d);
+        if (sb->rot_geom)
+            hipLaunchKernelGGL((k_build_low_sb<256, true>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, u_n, rhs_bstride,
+                               u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl, lmask, half_d);
+        else
+            hipLaunchKernelGGL((k_build_low_sb<256, false>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, u_n, rhs_bstride,
+                               u_bstride, ctx->d_ml, dt, ctx->d_L, ctx->d_D, ctx->d_b, ctx->d_xa, ctx->d_part, ctx->d_ctl, lmask, half_d);
         femfct_prof_end(ctx);
     } else if (!fused_build)
         LAUNCH_W(KC_BUILD_LOW, k_build_low, g, st, n, W, ctx->N, ctx->d_cols, ctx->d_tslot, A, N, nshared, rhs, u_n,
@@ -771,9 +788,14 @@ int femfct_enqueue_step_op(femfct_ctx* ctx, MatRef A, const SbOpArgs* sb, const 
     } else {
         if (sb) {
             femfct_prof_begin(ctx, KC_DUDT_RHS);
-            hipLaunchKernelGGL((k_dudt_rhs_sb<256>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, rhs_bstride,
-                               ctx->d_M, ctx->d_xa, ctx->d_xb, ulow, ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units,
-                               part_count, ipu, ctx->rel_tol, 1.25, 1.0, (const double*)nullptr, 0);
+            if (sb->rot_geom)
+                hipLaunchKernelGGL((k_dudt_rhs_sb<256, true>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, rhs_bstride,
+                                   ctx->d_M, ctx->d_xa, ctx->d_xb, ulow, ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units,
+                                   part_count, ipu, ctx->rel_tol, 1.25, 1.0, (const double*)nullptr, 0);
+            else
+                hipLaunchKernelGGL((k_dudt_rhs_sb<256, false>), g.grid, dim3(256), 0, st, n, ctx->N, ctx->h, *sb, rhs, rhs_bstride,
+                                   ctx->d_M, ctx->d_xa, ctx->d_xb, ulow, ctx->d_rdu, ctx->d_y1, ctx->d_part, ctx->d_ctl, units,
+                                   part_count, ipu, ctx->rel_tol, 1.25, 1.0, (const double*)nullptr, 0);
             femfct_prof_end(ctx);
         } else {
             LAUNCH_W(KC_DUDT_RHS, k_dudt_rhs, g, st, n, W, ctx->N, ctx->d_cols, A, rhs, rhs_bstride, ctx->d_M, ctx->d_xa,

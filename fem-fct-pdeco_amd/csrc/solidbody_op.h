@@ -18,6 +18,10 @@ struct SbOpArgs {
     VecRef c;               // control of this step (level-indirected), batch stride c_bstride
     int64_t c_bstride;
     double eps, sigma, rot_scale, bx, by;
+    // rot_geom: Arot is the rotation operator of the wind om * (-y, x) as femfct_assemble_rotation stores it, bit for
+    // bit (checked by the caller): the step kernels evaluate its rows from (ix, iy) instead of reading 56 B per row
+    int rot_geom;
+    double om, a1;          // angular velocity, lower-left corner of the mesh
 };
 
 #ifdef __HIPCC__
@@ -73,6 +77,38 @@ __device__ __forceinline__ void sb_drift_row(NodeXY p, int nc, double h, const d
                 double t2 = bgk * m12 * (ck[T.pl] + csum);
                 accT[T.slot[k]] += t1 + t2;
             }
+        }
+    });
+}
+
+// Rotation part in closed form.  The wind w = om * (-y, x) is linear, so on a triangle K
+//   int_K (w . grad lambda_P) lambda_k dx = grad lambda_P . |K|/12 (w_0 + w_1 + w_2 + w_k)        (w_k: wind at local node k)
+// -- the same integral the quadrature of k_convection_tab evaluates (exactly, up to rounding).  rot[s] = Arot[P, col(s)];
+// WITH_T: rotT[s] = Arot[col(s), P], the term row col(s) itself evaluates for its column P (same triangle, same local
+// numbering, the roles of the two local nodes swapped; two-term sums commute) => the bits of row col(s)'s entry.
+// No contraction: the expression tree below is what every kernel that inlines this evaluates.
+template <bool WITH_T>
+__device__ __forceinline__ void sb_rot_row(NodeXY p, int nc, double h, double a1, double om, double (&rot)[STENCIL_W],
+                                           double (&rotT)[STENCIL_W]) {
+#pragma clang fp contract(off)
+    const double c = h / 24.0;          // |K| / 12 / h
+#pragma unroll
+    for (int s = 0; s < STENCIL_W; ++s) { rot[s] = 0.0; rotT[s] = 0.0; }
+    for_each_tri(p, nc, [&](const TriInfo& T, int cx, int cy) {
+        double wx[3], wy[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double xk = a1 + (double)(cx + tri_nx(T.type, k)) * h;
+            const double yk = a1 + (double)(cy + tri_ny(T.type, k)) * h;
+            wx[k] = -om * yk;
+            wy[k] = om * xk;
+        }
+        const double Wx = (wx[0] + wx[1]) + wx[2], Wy = (wy[0] + wy[1]) + wy[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rot[T.slot[k]] += c * (tri_gx(T.type, T.pl) * (Wx + wx[k]) + tri_gy(T.type, T.pl) * (Wy + wy[k]));
+            if (WITH_T && k != T.pl)
+                rotT[T.slot[k]] += c * (tri_gx(T.type, k) * (Wx + wx[T.pl]) + tri_gy(T.type, k) * (Wy + wy[T.pl]));
         }
     });
 }

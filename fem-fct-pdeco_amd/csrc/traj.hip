@@ -166,8 +166,12 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
     // step k (level counter k) uses the control of level k+1 (finaltime.py:185): sequence entry k
     // bandwidth regime: the step kernels derive the operator from Arot and the control themselves (no stored A)
     bool inl = false;
+    int rotg = 0;
+    double rot_om = 0.0;
     auto begin = [&]() {
         inl = femfct_inline_ops_wanted(ctx, batch);     // (inside the sweep driver: depends on the kind's Jacobi kernel)
+        rotg = inl && Arot_ell && rot_scale != 0.0 && femfct_rotation_is_geometric(ctx, Arot, &rot_om);
+        ctx->last_rot_geom = rotg != 0;
         if (!inl)
             pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 1, eps, -1.0, rot_scale, bx, by, num_steps,
                                         batch, &Aall);
@@ -177,12 +181,14 @@ int femfct_solidbody_forward_src(femfct_ctx* ctx, const double* Arot_ell, const 
         femfct_ctx::GraphKey key{(uint64_t)2, key_bits(Arot), key_bits(c_traj), key_bits(c_shared), key_bits(u_traj),
                                  key_bits(num_steps), key_bits(dt), key_bits(eps), key_bits(rot_scale), key_bits(bx),
                                  key_bits(by), key_bits(batch), key_bits((int32_t)budget), key_bits(ctx->rel_tol),
-                                 key_bits(pre ? Aall.base : nullptr), key_bits(src_traj), key_bits((int32_t)inl)};
+                                 key_bits(pre ? Aall.base : nullptr), key_bits(src_traj), key_bits((int32_t)inl),
+                                 key_bits((int32_t)rotg), key_bits(rot_om)};
         return femfct_run_graph_reps(ctx, key, reps, +1, [&]() {
             // control at level n+1 (finaltime.py:185), state from level n into level n+1
             MatRef A = Aall;
             if (A.level) A.level_off += ctx->level_bias;
-            const SbOpArgs sb{Arot, ctx->d_Ad, lref(ctx, c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0, rot_scale, bx, by};
+            const SbOpArgs sb{Arot, ctx->d_Ad, lref(ctx, c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0, rot_scale, bx, by,
+                              rotg, rot_om, ctx->a1};
             if (!pre && !inl) {
                 femfct_enqueue_ops_solidbody(ctx, Arot, lref(ctx, c_traj, lv, n, 1), c_shared ? 0 : tstride, eps, -1.0,
                                              rot_scale, bx, by, ctx->d_trA, batch);
@@ -222,8 +228,12 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
     MatRef Aall{};
     bool pre = false;
     bool inl = false;
+    int rotg = 0;
+    double rot_om = 0.0;
     auto begin = [&]() {
         inl = femfct_inline_ops_wanted(ctx, batch);
+        rotg = inl && Arot_ell && rot_scale != 0.0 && femfct_rotation_is_geometric(ctx, Arot, &rot_om);
+        ctx->last_rot_geom = rotg != 0;
         // level counter n uses the control of level n (finaltime.py:213): sequence entry n
         if (!inl)
             pre = solidbody_preassemble(ctx, Arot, c_traj, c_shared, tstride, 0, eps, +1.0, rot_scale, bx, by, num_steps,
@@ -241,12 +251,13 @@ int femfct_solidbody_adjoint(femfct_ctx* ctx, const double* Arot_ell, const doub
                                  key_bits(uhat), key_bits(p_traj), key_bits(num_steps), key_bits(dt), key_bits(eps),
                                  key_bits(rot_scale), key_bits(bx), key_bits(by), key_bits(alltime), key_bits(batch),
                                  key_bits((int32_t)budget), key_bits(ctx->rel_tol), key_bits(pre ? Aall.base : nullptr),
-                                 key_bits((int32_t)inl)};
+                                 key_bits((int32_t)inl), key_bits((int32_t)rotg), key_bits(rot_om)};
         return femfct_run_graph_reps(ctx, key, reps, -1, [&]() {
             // level counter = n: control c_n (finaltime.py:213), p_{n+1} -> p_n
             MatRef A = Aall;
             if (A.level) A.level_off += ctx->level_bias;
-            const SbOpArgs sb{Arot, ctx->d_Ad, lref(ctx, c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0, rot_scale, bx, by};
+            const SbOpArgs sb{Arot, ctx->d_Ad, lref(ctx, c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0, rot_scale, bx, by,
+                              rotg, rot_om, ctx->a1};
             if (!pre && !inl) {
                 femfct_enqueue_ops_solidbody(ctx, Arot, lref(ctx, c_traj, lv, n, 0), c_shared ? 0 : tstride, eps, +1.0,
                                              rot_scale, bx, by, ctx->d_trA, batch);

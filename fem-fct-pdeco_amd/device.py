@@ -140,6 +140,12 @@ class Context:
         check(self.handle, lib.femfct_graph_replay_active(self.handle, C.byref(v)))
         return bool(v.value)
 
+    def rotation_derived(self) -> bool:
+        """True when the most recent solid-body sweep evaluated the rotation operator from the node positions."""
+        v = C.c_int(0)
+        check(self.handle, lib.femfct_rotation_derived(self.handle, C.byref(v)))
+        return bool(v.value)
+
     KERNEL_CLASSES = ("build_low", "jacobi", "dudt_rhs", "cheb", "flux", "limit", "assemble", "other")
 
     def set_profiling(self, enable: bool):
@@ -296,6 +302,15 @@ class Context:
         if out is None:
             out = self.empty(self.W * self.n)
         check(self.handle, lib.femfct_assemble_convection(self.handle, _host_ptr(w), float(scale), dptr(out)))
+        return out
+
+    def assemble_rotation(self, omega, out: DeviceArray | None = None) -> DeviceArray:
+        """``assemble_sparse(dot(wind, grad(v))*u*dx)`` for ``wind = omega * (-x[1], x[0])`` in closed form (equal to
+        :meth:`assemble_convection` of that wind up to rounding); the large-mesh step kernels recognise it and derive
+        its rows instead of loading them."""
+        if out is None:
+            out = self.empty(self.W * self.n)
+        check(self.handle, lib.femfct_assemble_rotation(self.handle, float(omega), dptr(out)))
         return out
 
     def drift_gradient_rhs(self, c, u, p, beta, out, levels, drift=(1.0, 1.0)):

@@ -41,9 +41,12 @@ class SolidBodyDrift:
         self.ctx.set_mesh_square(mesh.a1, mesh.a2, mesh.n_cells, order)
         self.n = self.ctx.n
         self.tlen = (self.num_steps + 1) * self.n
-        xq, yq = self.ctx.quad_points(mesh.n_cells)
-        wx, wy = (wind or rotation_wind(om))(xq, yq)
-        self.Arot = self.ctx.assemble_convection(np.stack([wx, wy], axis=1).reshape(-1))
+        if wind is None:        # 1/om * (-x[1], x[0]) (finaltime.py:91-93): linear, assembled in closed form
+            self.Arot = self.ctx.assemble_rotation(1.0 / om)
+        else:
+            xq, yq = self.ctx.quad_points(mesh.n_cells)
+            wx, wy = wind(xq, yq)
+            self.Arot = self.ctx.assemble_convection(np.stack([wx, wy], axis=1).reshape(-1))
 
     # -- device-resident API ---------------------------------------------------
     def new_traj(self, batch=None) -> DeviceArray:

@@ -98,6 +98,9 @@ int         femfct_set_graphs(femfct_ctx* ctx, int enable); /* hipGraph replay o
  * per side of the split Chebyshev launch (0: not split), out[3] halo depth.  No reference counterpart (diagnostic). */
 int         femfct_launch_info(const femfct_ctx* ctx, int32_t* out4_host);
 int         femfct_graph_replay_active(const femfct_ctx* ctx, int* active_host);
+/* 1 when the most recent femfct_solidbody_forward / _adjoint evaluated the rotation operator from the node positions
+ * (large meshes, operator from femfct_assemble_rotation), 0 when it loaded the stored array.  Diagnostic. */
+int         femfct_rotation_derived(const femfct_ctx* ctx, int* derived_host);
 /* multi-sweep fusion of the Jacobi / Chebyshev kernels: row strips (any banded pattern) and 2-D tiles
  * (structured mesh in vertex order); both default on, results agree with the one-sweep kernels to the
  * solver tolerance.  For tests and tuning. */
@@ -203,6 +206,12 @@ int femfct_mesh_quad_points(femfct_ctx* ctx, double* xq_host, double* yq_host);
 /* scale * assemble_sparse(dot(wind, grad(v))*u*dx)  (helpers.py:581,933,1015;
  * advection_solidbody_FCT_PDECO_finaltime.py:122); wind_q_host[.. *2 + {0,1}] at the points above. */
 int femfct_assemble_convection(femfct_ctx* ctx, const double* wind_q_host, double scale, double* A_ell_dev);
+/* The same form for the rigid rotation wind = omega * (-x[1], x[0]) (advection_solidbody_FCT_PDECO_finaltime.py:91-93,122
+ * with omega = 1/om) in closed form: the wind is linear, so int_K (w.grad v) u dx = grad v . |K|/12 (w_0 + w_1 + w_2 + w_k)
+ * -- the integral the quadrature above evaluates, equal to it up to rounding.  An operator assembled here is recognised
+ * (bit for bit) by femfct_solidbody_forward / _adjoint, whose large-mesh step kernels then evaluate its rows from the node
+ * positions instead of loading them (FEMFCT_GEOM_ROT=0: always load). */
+int femfct_assemble_rotation(femfct_ctx* ctx, double omega, double* A_ell_dev);
 /* rhs_dk = -(beta*M*c + assemble(p*dot(drift, grad(u))*v*dx)) for `levels` consecutive time levels
  * (advection_solidbody_FCT_PDECO_finaltime.py:228-236); feed to femfct_chebsi(batch=levels). */
 int femfct_drift_gradient_rhs(femfct_ctx* ctx, const double* c_dev, const double* u_dev, const double* p_dev,

@@ -379,7 +379,8 @@ def test_bandwidth_regime_self_selected_kernels_1025x1025_vs_oracle(hp, solvers,
 
 
 def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch):
-    """Four shortcuts of the bandwidth regime must not change a single bit: (i) FEMFCT_INLINE_OPS -- the drift
+    """Five shortcuts of the bandwidth regime must not change a single bit: (o) FEMFCT_GEOM_ROT -- the rotation operator
+    evaluated from the node positions in k_build_low_sb / k_dudt_rhs_sb instead of loaded; (i) FEMFCT_INLINE_OPS -- the drift
     operator derived inside k_build_low_sb / k_dudt_rhs_sb instead of stored by k_ops_solidbody and read back;
     (ii) FEMFCT_LMASK -- the exactly-zero off-diagonals of the upwind low-order operator neither stored nor loaded
     by the Jacobi patches; (iii) FEMFCT_HALF_D -- d_ij stored once per edge, the limiter takes d_ji from the
@@ -396,9 +397,11 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
         outs = []
         # (iv) FEMFCT_T4_WALKERS -- the persistent-workgroup launches (Jacobi with the LDS row carry, Chebyshev with
         # the look-ahead loads), forced onto this small mesh with 5 / 9 walkers, with and without the zero mask
-        for inline_ops, lmask, half_d, walkers in (("0", "0", "0", "100000"), ("1", "0", "0", "100000"), ("0", "1", "0", "100000"),
-                                                   ("0", "0", "1", "100000"), ("1", "1", "1", "100000"),
-                                                   ("0", "0", "0", "5"), ("1", "1", "1", "9")):
+        for inline_ops, lmask, half_d, walkers, geom_rot in (
+                ("0", "0", "0", "100000", "0"), ("1", "0", "0", "100000", "0"), ("1", "0", "0", "100000", "1"),
+                ("0", "1", "0", "100000", "1"), ("0", "0", "1", "100000", "1"), ("1", "1", "1", "100000", "1"),
+                ("0", "0", "0", "5", "1"), ("1", "1", "1", "9", "1"), ("1", "1", "1", "9", "0")):
+            monkeypatch.setenv("FEMFCT_GEOM_ROT", geom_rot)
             monkeypatch.setenv("FEMFCT_INLINE_OPS", inline_ops)
             monkeypatch.setenv("FEMFCT_LMASK", lmask)
             monkeypatch.setenv("FEMFCT_HALF_D", half_d)
@@ -411,6 +414,8 @@ def test_bandwidth_regime_shortcuts_are_bitwise_neutral(hp, solvers, monkeypatch
                 uk[:n] = u0
                 prob.solve_state(c, uk)
                 pk = prob.solve_adjoint(c, uk, 0.9 * uk + 0.01, np.zeros_like(uk), optim="alltime")
+                if _fusion_knobs_on():
+                    assert prob.ctx.rotation_derived() == (inline_ops == "1" and geom_rot == "1")
                 outs.append((uk.copy(), pk.copy()))
             finally:
                 prob.close()

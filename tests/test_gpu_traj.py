@@ -78,6 +78,10 @@ def test_mesh_constants_and_convection(hp, order, nc, a1, a2):
         A = ctx.assemble_convection(np.stack([wx, wy], axis=1).reshape(-1))
         Ao = asm.convection(wind)
         assert abs(to_dof(ell_to_scipy(ctx, A, n)) - Ao).max() < 1e-13 * max(1.0, abs(Ao).max())
+    # the rigid rotation in closed form (femfct_assemble_rotation): the same integral as the quadrature, to rounding
+    Ar = ctx.assemble_rotation(40.0 / np.pi)
+    Ao = asm.convection(rotation_wind(np.pi / 40))
+    assert abs(to_dof(ell_to_scipy(ctx, Ar, n)) - Ao).max() < 1e-14 * max(1.0, abs(Ao).max())
     ctx.close()
 
 
