@@ -410,7 +410,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250,
                     help="forward+adjoint oracle steps each; 250 = the whole C2 sweep, ~10 s of one core (0: skip)")
     ap.add_argument("--pgd-iters", type=int, default=5, help="projected-gradient iterations of the C2 problem (0: skip)")
-    ap.add_argument("--batched", type=str, default="8,64", help="extra batch sizes reported in 'batched' ('' : skip)")
+    ap.add_argument("--batched", type=str, default="8,64,256", help="extra batch sizes reported in 'batched' ('' : skip)")
     ap.add_argument("--tolerance-table", type=int, default=1, help="1: low-order solve tolerance 1e-13 / 1e-11 / 1e-9: sweeps, large-mesh steps/s, C2 parity")
     ap.add_argument("--systems", type=int, default=1, help="1: add configs 3 and 4 (Schnakenberg, chemotaxis; 41x41, 200 + 200 steps) as 'systems'")
     ap.add_argument("--force-dist", action="store_true",

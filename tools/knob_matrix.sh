@@ -15,11 +15,11 @@ cd $REPO
 SKIP='not pgd_loop and not self_selected and not mimura and not c2_solidbody_81x81 and not c3_schnakenberg and not c4_chemotaxis'
 A=("FEMFCT_TILES=0" "FEMFCT_STRIPS=0" "FEMFCT_IMPLICIT=0" "FEMFCT_TILE4=0" "FEMFCT_TILE4=2" "FEMFCT_T4_DPP=0" "FEMFCT_GEOM_MASS=0" "FEMFCT_T4_XCD=1" "FEMFCT_FUSE_BUILD=0" "FEMFCT_FUSE_DUDT=0")
 B=("FEMFCT_FUSE_FLUX=0" "FEMFCT_FUSE_END=0" "FEMFCT_DEEP_HALO=0" "FEMFCT_DEFER_CHECK=0" "FEMFCT_INLINE_OPS=0" "FEMFCT_LMASK=0" "FEMFCT_HALF_D=0" "FEMFCT_T4_WALK=0" "FEMFCT_T4_PAIR=0")
-C=("FEMFCT_T4_INT=0" "FEMFCT_T4_SNAKE=0" "FEMFCT_T4_STAGGER_US=0" "FEMFCT_SPECIES_SOLVER=1" "FEMFCT_MESH_SOLVE=0" "FEMFCT_PREASSEMBLE=0" "FEMFCT_EXACT=1" "FEMFCT_STEPS_PER_GRAPH=1" "FEMFCT_MESH_STEP=0")
+C=("FEMFCT_GEOM_ROT=0" "FEMFCT_T4_INT=0" "FEMFCT_T4_SNAKE=0" "FEMFCT_T4_STAGGER_US=0" "FEMFCT_SPECIES_SOLVER=1" "FEMFCT_MESH_SOLVE=0" "FEMFCT_PREASSEMBLE=0" "FEMFCT_EXACT=1" "FEMFCT_STEPS_PER_GRAPH=1" "FEMFCT_MESH_STEP=0")
 F1=("FEMFCT_MESH_STEP=0" "FEMFCT_T4_PAIR=0" "FEMFCT_T4_WALK=0")
 F2=("FEMFCT_LMASK=0" "FEMFCT_HALF_D=0" "FEMFCT_T4_INT=0")
 F3=("FEMFCT_INLINE_OPS=0" "FEMFCT_TILE4=0")
-F4=("FEMFCT_TILE4=2" "FEMFCT_MESH_STEP_BATCH=8")
+F4=("FEMFCT_TILE4=2" "FEMFCT_MESH_STEP_BATCH=8" "FEMFCT_GEOM_ROT=0")
 FULL=0
 case $PART in a) SET=("${A[@]}");; b) SET=("${B[@]}");; c) SET=("${C[@]}");;
   f1) SET=("${F1[@]}"); FULL=1;; f2) SET=("${F2[@]}"); FULL=1;; f3) SET=("${F3[@]}"); FULL=1;; f4) SET=("${F4[@]}"); FULL=1;;

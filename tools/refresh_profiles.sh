@@ -43,6 +43,8 @@ cp $(find $OUT/kb -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_batch64
 echo "[refresh] the other systems' sweeps under the same profiler command that used to fault (DESIGN.md section 9)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -- python3 $REPO/tools/bench_systems.py > $OUT/${TAG}_systems_under_rocprof.txt 2>&1 && echo "exit code 0" >> $OUT/${TAG}_systems_under_rocprof.txt || echo "exit code $? (non-zero)" >> $OUT/${TAG}_systems_under_rocprof.txt
 cp $(find $OUT/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_systems_kernel_stats.csv 2>/dev/null || true
+echo "[refresh] the same sweeps without the profiler (graphs replayed)"
+timeout -k 10 300 python3 $REPO/tools/bench_systems.py > $OUT/${TAG}_systems.txt 2>&1
 echo "[refresh] kernel trace at 41 x 41 (configs 3 / 4): one workgroup per trajectory vs the tile path, 1 / 64 / 256 trajectories per launch"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/km -- python3 $REPO/tools/mesh_step_check.py 40 50 1,64,256 > $OUT/${TAG}_mesh41_under_rocprof.txt 2> $OUT/km.err
 cp $(find $OUT/km -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_mesh41_kernel_stats.csv
