@@ -740,13 +740,26 @@ def cpu_baseline_sweep(n_proc, workload, sample):
                               stdout=subprocess.PIPE, text=True, env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES=""))
              for k in range(n_proc)]
     t0 = time.perf_counter()
-    outs = [p.communicate()[0] for p in procs]
+    # a worker that hangs must not hang the bench: the sample is sized for tens of seconds; past the limit it is killed and
+    # reported (workers_ok < cores, 'error')
+    limit = max(300.0, 4.0 * sample)
+    outs, errors = [], []
+    for k, p in enumerate(procs):
+        try:
+            outs.append(p.communicate(timeout=max(1.0, limit - (time.perf_counter() - t0)))[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0])
+            errors.append(f"worker {k}: killed after {limit:.0f} s")
+            continue
+        if p.returncode != 0:
+            errors.append(f"worker {k}: exit code {p.returncode}")
     wall = time.perf_counter() - t0
     recs = [json.loads(o.strip().splitlines()[-1]) for o, p in zip(outs, procs) if p.returncode == 0 and o.strip()]
     steps = sum(r["steps"] for r in recs)
     slowest = max((r["seconds"] for r in recs), default=float("nan"))
     return {"value": steps / slowest if recs else None, "unit": "timesteps/s", "cores": n_proc, "kind": "port",
-            "host_cpus": os.cpu_count(), "workers_ok": len(recs),
+            "host_cpus": os.cpu_count(), "workers_ok": len(recs), **({"error": "; ".join(errors)} if errors else {}),
             "sample": f"{n_proc} concurrent 1-thread oracle processes, each {sample} forward + {sample} adjoint FCT steps of the "
                       f"{workload.upper()} workload (per-step assembly + vectorised NumPy/SciPy FCT step with SuperLU); "
                       "value = all steps / the slowest worker's time",

@@ -74,12 +74,14 @@ struct femfct_ctx {
     // the batch straddles the wrap (host SIGSEGV inside librocprofiler-sdk.so; DESIGN.md section 9,
     // tools/graph_intercept_probe.hip reproduces it without this library).  FEMFCT_PROFILER_GRAPHS=1 overrides.
     bool graphs_blocked = false;
+    bool profiler_graphs_ok = false;   // FEMFCT_PROFILER_GRAPHS=1
     int32_t steps_per_graph = 50;   // time steps captured per hipGraph in the trajectory drivers (only the last one moves the counters)
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
     bool use_tiles = true;      // 2-D tile variant (structured mesh, vertex order)
     bool mesh_solve = true;         // species solves of meshes with n <= 4096 as one workgroup per system (FEMFCT_MESH_SOLVE)
     bool mesh_solve_attr[8] = {false, false, false, false, false, false, false, false};
     int single_patch_min_batch = 8; // whole-mesh workgroups (N <= 48) for species solves from this batch size on (FEMFCT_SINGLE_PATCH_BATCH; 0 = off)
+    bool form_groups = true;    // FEMFCT_FORM_GROUPS: independent quadrature forms of a time step share one launch (forms.h: FormGroup)
     bool geom_rot = true;       // FEMFCT_GEOM_ROT: bandwidth-regime step kernels derive the rotation operator from (ix, iy)
     double rot_om = 0.0;        // angular velocity of the last femfct_assemble_rotation
     bool rot_om_set = false;
@@ -313,11 +315,17 @@ int femfct_enqueue_step(femfct_ctx* ctx, const double* A, const double* N, int32
                         const double* rhs, const double* u_n, double dt, double* u_out,
                         int32_t batch, int32_t budget);
 
+bool femfct_profiler_attached();   // ctx.hip: a rocprofiler-sdk tool is resident in this process
+
 template <class F>
 int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enqueue) {
     if (!ctx->use_graphs || ctx->prof_on || ctx->graphs_blocked) return enqueue();
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
+        if (!ctx->profiler_graphs_ok && femfct_profiler_attached()) {      // a tool attached since femfct_create
+            ctx->graphs_blocked = true;
+            return enqueue();
+        }
         if (ctx->graphs.size() > 64) femfct_drop_graphs(ctx);
         hipGraph_t graph = nullptr;
         HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));

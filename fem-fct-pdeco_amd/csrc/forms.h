@@ -31,13 +31,44 @@ struct LoadSpec {
     int64_t mx_bs = 0, p1_bs = 0, q1_bs = 0, q2_bs = 0, q3_bs = 0, da_bs = 0, db_bs = 0, ea_bs = 0, eb_bs = 0;
 };
 
+// up to three independent forms of a time step in one launch (kernels_forms.hip: k_forms2 / k_forms3)
+enum { FORM_NONE = 0, FORM_WMASS, FORM_LOAD, FORM_CHTXS_MAT0, FORM_CHTXS_MAT1 };
+struct ChtxsMatSpec {
+    VecRef u{nullptr, nullptr, 0, 0}, v{nullptr, nullptr, 0, 0};
+    int64_t u_bs = 0, v_bs = 0;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;      // Dm, chi, eta
+};
+struct FormJob {
+    int type = FORM_NONE;
+    int batch = 0;
+    double* out = nullptr;
+    WMassSpec w;
+    LoadSpec l;
+    ChtxsMatSpec c;
+};
+// Collects forms and launches them together; forms of one group must not depend on each other's output.
+// (FEMFCT_FORM_GROUPS=0: every form in its own launch, in the order given -- the same bits.)
+struct FormGroup {
+    femfct_ctx* ctx;
+    int n = 0;
+    FormJob jobs[3];
+    explicit FormGroup(femfct_ctx* c) : ctx(c) {}
+    void weighted_mass(const WMassSpec& sp, double* out, int32_t batch);
+    void load(const LoadSpec& sp, double* out, int32_t batch);
+    void chtxs_matrix(int adjoint, VecRef u, int64_t u_bs, VecRef v, int64_t v_bs, double Dm, double chi, double eta,
+                      double* out, int32_t batch);
+    int launch();
+};
+
 MeshArgs femfct_mesh_args(const femfct_ctx* ctx);
 int femfct_enqueue_weighted_mass(femfct_ctx* ctx, const WMassSpec& sp, double* out, int32_t batch);
 int femfct_enqueue_load(femfct_ctx* ctx, const LoadSpec& sp, double* out, int32_t batch);
 int femfct_enqueue_chtxs_matrix(femfct_ctx* ctx, int adjoint, VecRef u, int64_t u_bs, VecRef v, int64_t v_bs,
                                 double Dm, double chi, double eta, double* out, int32_t batch);
+// mx.base != null: out = s0 * M mx + s2 * rhs_q in the same pass (the species right-hand side, helpers.py:1538)
 int femfct_enqueue_chtxs_rhs_q(femfct_ctx* ctx, VecRef u, int64_t u_bs, VecRef p, int64_t p_bs, double chi, double eta,
-                               VecRef da, int64_t da_bs, VecRef db, int64_t db_bs, double* out, int32_t batch);
+                               VecRef da, int64_t da_bs, VecRef db, int64_t db_bs, double* out, int32_t batch,
+                               VecRef mx = VecRef{nullptr, nullptr, 0, 0}, int64_t mx_bs = 0, double s0 = 0.0, double s2 = 0.0);
 
 // Jacobi-preconditioned BiCGStab for the non-FCT implicit solves (kernels_krylov.hip)
 struct KrylovCtl {

@@ -14,6 +14,7 @@
 #include "forms.h"
 
 #include <math.h>
+#include <algorithm>
 
 namespace {
 
@@ -51,8 +52,8 @@ __device__ __forceinline__ const double* bptr(const VecRef& r, int64_t bstride, 
 // ---------------------------------------------------------------------------
 // out = alpha*M + gamma*Base + beta * int f1_h f2_h phi_i phi_j
 // ---------------------------------------------------------------------------
-__global__ void k_weighted_mass(MeshArgs m, WMassSpec sp, double* __restrict__ out_) {
-    const int bz = blockIdx.y, n = m.n;
+__device__ __forceinline__ void form_weighted_mass(const MeshArgs& m, const WMassSpec& sp, double* __restrict__ out_, int bz) {
+    const int n = m.n;
     const double* f1 = bptr(sp.f1, sp.f1_bs, bz);
     const double* f2 = bptr(sp.f2, sp.f2_bs, bz);
     double* out = out_ + (int64_t)bz * STENCIL_W * n;
@@ -94,8 +95,8 @@ __global__ void k_weighted_mass(MeshArgs m, WMassSpec sp, double* __restrict__ o
 // (q3 may be absent = 1).  The raw nodal difference reproduces helpers.py:1506-1507,1533-1534; the
 // mass-weighted one is assemble((ea_h - eb_h)*w*dx) (Schnak_FCT_PDECO_alltime.py:268,278).
 // ---------------------------------------------------------------------------
-__global__ void k_load(MeshArgs m, LoadSpec sp, double* __restrict__ out_) {
-    const int bz = blockIdx.y, n = m.n;
+__device__ __forceinline__ void form_load(const MeshArgs& m, const LoadSpec& sp, double* __restrict__ out_, int bz) {
+    const int n = m.n;
     const double* mx = bptr(sp.mx, sp.mx_bs, bz);
     const double* p1 = bptr(sp.p1, sp.p1_bs, bz);
     const double* q1 = bptr(sp.q1, sp.q1_bs, bz);
@@ -166,9 +167,9 @@ __global__ void k_load(MeshArgs m, LoadSpec sp, double* __restrict__ out_) {
 //   A = Dm*Ad - chi * int (1 - eta u_h) exp(-eta u_h) (grad phi_j . grad v_h) phi_i   (7-point rule)
 // ---------------------------------------------------------------------------
 template <int ADJ>
-__global__ void k_chtxs_matrix(MeshArgs m, VecRef u_ref, int64_t u_bs, VecRef v_ref, int64_t v_bs, double Dm,
-                               double chi, double eta, double* __restrict__ out_) {
-    const int bz = blockIdx.y, n = m.n;
+__device__ __forceinline__ void form_chtxs_matrix(const MeshArgs& m, VecRef u_ref, int64_t u_bs, VecRef v_ref, int64_t v_bs, double Dm,
+                                                  double chi, double eta, double* __restrict__ out_, int bz) {
+    const int n = m.n;
     const double* u = bptr(u_ref, u_bs, bz);
     const double* v = bptr(v_ref, v_bs, bz);
     double* out = out_ + (int64_t)bz * STENCIL_W * n;
@@ -218,10 +219,13 @@ __global__ void k_chtxs_matrix(MeshArgs m, VecRef u_ref, int64_t u_bs, VecRef v_
 
 // chemotaxis adjoint rhs for q (helpers.py:1531-1534):
 //   out_i = int chi u_h exp(-eta u_h) (grad p_h . grad phi_i)  [+ (da_i - db_i)]    (6-point rule)
-__global__ void k_chtxs_rhs_q(MeshArgs m, VecRef u_ref, int64_t u_bs, VecRef p_ref, int64_t p_bs, double chi,
-                              double eta, VecRef da_ref, int64_t da_bs, VecRef db_ref, int64_t db_bs,
-                              double* __restrict__ out_) {
-    const int bz = blockIdx.y, n = m.n;
+// mx_ref != null: the species right-hand side in one pass, out_i = s0 * (M mx)_i + s2 * rhs_q_i (helpers.py:1538) -- the
+// expressions of k_load applied to this row's own value, so the bits of the two-launch sequence
+__device__ __forceinline__ void form_chtxs_rhs_q(const MeshArgs& m, VecRef u_ref, int64_t u_bs, VecRef p_ref, int64_t p_bs, double chi,
+                                                 double eta, VecRef da_ref, int64_t da_bs, VecRef db_ref, int64_t db_bs,
+                                                 VecRef mx_ref, int64_t mx_bs, double s0, double s2, double* __restrict__ out_, int bz) {
+    const int n = m.n;
+    const double* mx = bptr(mx_ref, mx_bs, bz);
     const double* u = bptr(u_ref, u_bs, bz);
     const double* pp = bptr(p_ref, p_bs, bz);
     const double* da = bptr(da_ref, da_bs, bz);
@@ -250,8 +254,55 @@ __global__ void k_chtxs_rhs_q(MeshArgs m, VecRef u_ref, int64_t u_bs, VecRef p_r
             res += t * gpp;
         });
         if (da) res += da[i] - (db ? db[i] : 0.0);
+        if (mx) {
+            double fin = 0.0;
+            if (s0 != 0.0) {
+                double acc = m.M[i] * mx[i];
+#pragma unroll
+                for (int s = 1; s < STENCIL_W; ++s) {
+                    int64_t idx = (int64_t)s * n + i;
+                    acc += m.M[idx] * mx[m.cols[idx]];
+                }
+                fin += s0 * acc;
+            }
+            if (s2 != 0.0) fin += s2 * (res - 0.0);
+            res = fin;
+        }
         out[i] = res;
     }
+}
+
+// ---------------------------------------------------------------------------
+// the kernels: one form per launch, or up to three independent forms in ONE launch (blockIdx.z picks the job): on the
+// config meshes a form is ~1 us of work inside ~5 us of launch latency, and the forms of a time step that depend only
+// on earlier levels can share it (FormGroup, forms.h)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void run_form(const MeshArgs& m, const FormJob& j, int bz) {
+    if (bz >= j.batch) return;
+    switch (j.type) {
+        case FORM_WMASS: form_weighted_mass(m, j.w, j.out, bz); break;
+        case FORM_LOAD: form_load(m, j.l, j.out, bz); break;
+        case FORM_CHTXS_MAT0: form_chtxs_matrix<0>(m, j.c.u, j.c.u_bs, j.c.v, j.c.v_bs, j.c.p0, j.c.p1, j.c.p2, j.out, bz); break;
+        case FORM_CHTXS_MAT1: form_chtxs_matrix<1>(m, j.c.u, j.c.u_bs, j.c.v, j.c.v_bs, j.c.p0, j.c.p1, j.c.p2, j.out, bz); break;
+        default: break;
+    }
+}
+
+__global__ void k_weighted_mass(MeshArgs m, WMassSpec sp, double* __restrict__ out_) { form_weighted_mass(m, sp, out_, blockIdx.y); }
+__global__ void k_load(MeshArgs m, LoadSpec sp, double* __restrict__ out_) { form_load(m, sp, out_, blockIdx.y); }
+template <int ADJ>
+__global__ void k_chtxs_matrix(MeshArgs m, VecRef u_ref, int64_t u_bs, VecRef v_ref, int64_t v_bs, double Dm, double chi,
+                               double eta, double* __restrict__ out_) {
+    form_chtxs_matrix<ADJ>(m, u_ref, u_bs, v_ref, v_bs, Dm, chi, eta, out_, blockIdx.y);
+}
+__global__ void k_chtxs_rhs_q(MeshArgs m, VecRef u_ref, int64_t u_bs, VecRef p_ref, int64_t p_bs, double chi, double eta,
+                              VecRef da_ref, int64_t da_bs, VecRef db_ref, int64_t db_bs, VecRef mx_ref, int64_t mx_bs,
+                              double s0, double s2, double* __restrict__ out_) {
+    form_chtxs_rhs_q(m, u_ref, u_bs, p_ref, p_bs, chi, eta, da_ref, da_bs, db_ref, db_bs, mx_ref, mx_bs, s0, s2, out_, blockIdx.y);
+}
+__global__ void k_forms2(MeshArgs m, FormJob j0, FormJob j1) { run_form(m, blockIdx.z == 0 ? j0 : j1, blockIdx.y); }
+__global__ void k_forms3(MeshArgs m, FormJob j0, FormJob j1, FormJob j2) {
+    run_form(m, blockIdx.z == 0 ? j0 : (blockIdx.z == 1 ? j1 : j2), blockIdx.y);
 }
 
 }  // namespace
@@ -294,11 +345,65 @@ int femfct_enqueue_chtxs_matrix(femfct_ctx* ctx, int adjoint, VecRef u, int64_t 
 }
 
 int femfct_enqueue_chtxs_rhs_q(femfct_ctx* ctx, VecRef u, int64_t u_bs, VecRef p, int64_t p_bs, double chi, double eta,
-                               VecRef da, int64_t da_bs, VecRef db, int64_t db_bs, double* out, int32_t batch) {
+                               VecRef da, int64_t da_bs, VecRef db, int64_t db_bs, double* out, int32_t batch,
+                               VecRef mx, int64_t mx_bs, double s0, double s2) {
     LaunchGeom g = femfct_geom(ctx, batch);
     femfct_prof_begin(ctx, KC_ASSEMBLE);
     hipLaunchKernelGGL(k_chtxs_rhs_q, g.grid, g.block, 0, ctx->stream, femfct_mesh_args(ctx), u, u_bs, p, p_bs, chi, eta,
-                       da, da_bs, db, db_bs, out);
+                       da, da_bs, db, db_bs, mx, mx_bs, s0, s2, out);
     femfct_prof_end(ctx);
+    return FEMFCT_OK;
+}
+
+// ------------------------------------------------------------------ FormGroup
+void FormGroup::weighted_mass(const WMassSpec& sp, double* out, int32_t batch) {
+    if (n == 3) launch();
+    FormJob& j = jobs[n++];
+    j = FormJob{};
+    j.type = FORM_WMASS; j.batch = batch; j.out = out; j.w = sp;
+}
+
+void FormGroup::load(const LoadSpec& sp, double* out, int32_t batch) {
+    if (n == 3) launch();
+    FormJob& j = jobs[n++];
+    j = FormJob{};
+    j.type = FORM_LOAD; j.batch = batch; j.out = out; j.l = sp;
+}
+
+void FormGroup::chtxs_matrix(int adjoint, VecRef u, int64_t u_bs, VecRef v, int64_t v_bs, double Dm, double chi, double eta,
+                             double* out, int32_t batch) {
+    if (n == 3) launch();
+    FormJob& j = jobs[n++];
+    j = FormJob{};
+    j.type = adjoint ? FORM_CHTXS_MAT1 : FORM_CHTXS_MAT0; j.batch = batch; j.out = out;
+    j.c.u = u; j.c.u_bs = u_bs; j.c.v = v; j.c.v_bs = v_bs; j.c.p0 = Dm; j.c.p1 = chi; j.c.p2 = eta;
+}
+
+int FormGroup::launch() {
+    const int cnt = n;
+    n = 0;
+    if (cnt == 0) return FEMFCT_OK;
+    if (cnt == 1 || !ctx->form_groups) {          // one form, or FEMFCT_FORM_GROUPS=0: the forms' own kernels, in order
+        for (int k = 0; k < cnt; ++k) {
+            const FormJob& j = jobs[k];
+            int r = FEMFCT_OK;
+            if (j.type == FORM_WMASS) r = femfct_enqueue_weighted_mass(ctx, j.w, j.out, j.batch);
+            else if (j.type == FORM_LOAD) r = femfct_enqueue_load(ctx, j.l, j.out, j.batch);
+            else r = femfct_enqueue_chtxs_matrix(ctx, j.type == FORM_CHTXS_MAT1, j.c.u, j.c.u_bs, j.c.v, j.c.v_bs, j.c.p0, j.c.p1,
+                                                 j.c.p2, j.out, j.batch);
+            if (r != FEMFCT_OK) return r;
+        }
+        return FEMFCT_OK;
+    }
+    int32_t bmax = 1;
+    for (int k = 0; k < cnt; ++k) bmax = std::max(bmax, jobs[k].batch);
+    LaunchGeom g = femfct_geom(ctx, bmax);
+    g.grid.z = cnt;
+    femfct_prof_begin(ctx, KC_ASSEMBLE);
+    if (cnt == 2) hipLaunchKernelGGL(k_forms2, g.grid, g.block, 0, ctx->stream, femfct_mesh_args(ctx), jobs[0], jobs[1]);
+    else hipLaunchKernelGGL(k_forms3, g.grid, g.block, 0, ctx->stream, femfct_mesh_args(ctx), jobs[0], jobs[1], jobs[2]);
+    femfct_prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "form group launch failed: %s", hipGetErrorString(e));
     return FEMFCT_OK;
 }

@@ -11,6 +11,7 @@
 #include "femfct_internal.h"
 #include "device_utils.h"
 #include "forms.h"
+#include "step_end.h"
 
 #include <math.h>
 
@@ -459,8 +460,11 @@ __global__ void __launch_bounds__(1024)
 k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double* __restrict__ A_, int ashared,
                   const double* __restrict__ b_, VecRef x0_ref, int64_t x0_bs, VecRef out_ref, int64_t out_bs,
                   const double* __restrict__ Mdiag, const double* __restrict__ Kdiag, double tau, double lam_e, double lmax,
-                  int K, double rel_tol, KrylovCtl* __restrict__ ctl_) {
+                  int K, double rel_tol, KrylovCtl* __restrict__ ctl_, EndArgs e) {
     constexpr int CHECK = 16, W = 7;      // structured P1 mesh: seven slots (checked by the launcher)
+    // e.level != null: this solve is the last operation of its time step -- every workgroup logs its own records and the
+    // last one of the graph's last step moves the time level (as k_mesh_step does); the ordinal is read before anything else
+    const int ord = e.level ? e.level[1] + e.ord_off : 0;
     extern __shared__ double ybuf[];          // 2 * n doubles: the iterate the neighbours read, and the next one
     __shared__ double smem[32];
     const int bz = blockIdx.x;
@@ -571,6 +575,23 @@ k_mesh_cheb_solve(int n, int Wrt, const int32_t* __restrict__ cols, const double
             c->iters = (int)ceil(fmin(fmax(need, 1.0), 1.0e6));
             c->flags |= FEMFCT_FLAG_SOLVER_BUDGET;
         }
+        if (e.level) e.klog[(int64_t)ord * e.batch + bz] = *c;
+    }
+    if (e.level) {
+        const uint32_t* cs = reinterpret_cast<const uint32_t*>(e.ctl + bz);        // the FCT step's record (an earlier kernel's)
+        uint32_t* cd = reinterpret_cast<uint32_t*>(e.log + (int64_t)ord * e.batch + bz);
+        if (threadIdx.x >= 64 && threadIdx.x < 80) cd[threadIdx.x - 64] = cs[threadIdx.x - 64];
+        if (e.ord_adv != 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (atomicAdd(e.ticket, 1u) == gridDim.x - 1) {
+                    e.level[0] += e.delta;
+                    e.level[1] = (ord - e.ord_off) + e.ord_adv;
+                    *e.ticket = 0u;
+                }
+            }
+        }
     }
 }
 
@@ -586,6 +607,15 @@ static int enqueue_mesh_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t m
     const double lam_e = tau >= 0.0 ? element_lambda_min(ctx->h, tau) : 0.5;
     const size_t lds = (size_t)2 * n * sizeof(double);
     KrylovCtl* ctl = (KrylovCtl*)ctx->d_kry_ctl;
+    // last operation of a time step (femfct_request_fused_end): the kernel logs and advances itself, no k_step_end launch
+    EndArgs e{};
+    const bool fuse_end = ctx->end_req_delta != 0 && ctx->end_req_krylov && ctx->d_ticket && ctx->d_level && ctx->d_log &&
+                          ctx->d_klog && !ctx->prof_on;
+    if (fuse_end) {
+        e.level = ctx->d_level; e.delta = ctx->rep_last ? ctx->end_req_delta * ctx->rep_total : 0;
+        e.ord_adv = ctx->rep_last ? ctx->rep_total : 0; e.ord_off = ctx->ord_bias; e.ctl = ctx->d_ctl; e.log = ctx->d_log;
+        e.kctl = ctl; e.klog = (KrylovCtl*)ctx->d_klog; e.batch = batch; e.ticket = ctx->d_ticket;
+    }
     femfct_prof_begin(ctx, KC_OTHER);
 #define MS(NPT)                                                                                                          \
     do {                                                                                                                 \
@@ -595,13 +625,14 @@ static int enqueue_mesh_cheb_solve(femfct_ctx* ctx, const double* mat, int32_t m
         ctx->mesh_solve_attr[NPT] = true;                                                                                \
         hipLaunchKernelGGL((k_mesh_cheb_solve<NPT>), dim3(batch), dim3(1024), lds, ctx->stream, n, W, ctx->d_cols, mat,  \
                            mat_shared, b, x0, x0_bs, x_out, out_bs, (const double*)ctx->d_M, (const double*)ctx->d_Ad, tau, \
-                           lam_e, 2.2, (int)budget, ctx->kry_tol, ctl);                                                  \
+                           lam_e, 2.2, (int)budget, ctx->kry_tol, ctl, e);                                               \
     } while (0)
     MS(2);
 #undef MS
     femfct_prof_end(ctx);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "Chebyshev solve launch failed: %s", hipGetErrorString(e));
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return femfct_fail(ctx, FEMFCT_ERR_HIP, "Chebyshev solve launch failed: %s", hipGetErrorString(err));
+    if (fuse_end) ctx->end_fused = true;
     return FEMFCT_OK;
 }
 

@@ -295,17 +295,21 @@ int femfct_schnak_forward_tw(femfct_ctx* ctx, const double* Aw_ell, const double
             l1.s1 = 1.0; l1.k1 = gam / rescaling; l1.p1 = make_ref(c_level); l1.p1_bs = n;
             l1.k2 = gam; l1.q1 = L(u_traj, 0); l1.q2 = L(u_traj, 0); l1.q3 = L(v_traj, 0);
             l1.q1_bs = l1.q2_bs = l1.q3_bs = ts;
-            femfct_enqueue_load(ctx, l1, ctx->d_trRhs, batch);
-            int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, ctx->d_trN, 1, make_ref(ctx->d_trRhs), n, L(u_traj, 0), ts,
-                                            dt, L(u_traj, 1), ts, batch, budget);
+            LoadSpec l2;  // M@v_n + dt*assemble(gamma*c_b*v*dx)  (helpers.py:594,596): level n only, so it rides in l1's launch
+            l2.s0 = 1.0; l2.mx = L(v_traj, 0); l2.mx_bs = ts; l2.s1 = dt; l2.k0 = gam * c_b;
+            FormGroup fg(ctx);
+            fg.load(l1, ctx->d_trRhs, batch);
+            fg.load(l2, ctx->d_trRhs2, batch);
+            int r = fg.launch();
+            if (r != FEMFCT_OK) return r;
+            r = femfct_enqueue_step_ref(ctx, ctx->d_trA, ctx->d_trN, 1, make_ref(ctx->d_trRhs), n, L(u_traj, 0), ts,
+                                        dt, L(u_traj, 1), ts, batch, budget);
             if (r != FEMFCT_OK) return r;
             WMassSpec ws;  // Mat_var2 = Base2 + dt*gamma*M_u2(u_{n+1})  (helpers.py:591,595)
             ws.gamma = 1.0; ws.base = ctx->d_trBase; ws.beta = dt * gam;
             ws.f1 = L(u_traj, 1); ws.f2 = L(u_traj, 1); ws.f1_bs = ws.f2_bs = ts;
             femfct_enqueue_weighted_mass(ctx, ws, ctx->d_trMat, batch);
-            LoadSpec l2;  // M@v_n + dt*assemble(gamma*c_b*v*dx)  (helpers.py:594,596)
-            l2.s0 = 1.0; l2.mx = L(v_traj, 0); l2.mx_bs = ts; l2.s1 = dt; l2.k0 = gam * c_b;
-            femfct_enqueue_load(ctx, l2, ctx->d_trRhs2, batch);
+            femfct_request_fused_end(ctx, 1, true);       // (the one-launch species solve logs and advances itself)
             r = femfct_enqueue_species_solve(ctx, 12, ctx->d_trMat, 0, ctx->d_trRhs2, L(v_traj, 0), ts, L(v_traj, 1), ts, batch, kbudget, dt * Dv);
             if (r != FEMFCT_OK) return r;
             return femfct_enqueue_step_end(ctx, 1, batch, true);
@@ -379,18 +383,22 @@ int femfct_schnak_adjoint_tw(femfct_ctx* ctx, const double* AwT_ell, const doubl
             WMassSpec wq;
             wq.gamma = 1.0; wq.base = ctx->d_trBase; wq.beta = dt * gam;
             wq.f1 = L(u_traj, 0); wq.f2 = L(u_traj, 0); wq.f1_bs = wq.f2_bs = ts;
-            femfct_enqueue_weighted_mass(ctx, wq, ctx->d_trMat, batch);
             LoadSpec lq;  // M@q_{n+1} + dt*assemble(gamma*p_{n+1}*u_n^2*w*dx)
             lq.s0 = 1.0; lq.mx = L(q_traj, 1); lq.mx_bs = ts; lq.s1 = dt; lq.k2 = gam;
             lq.q1 = L(p_traj, 1); lq.q2 = L(u_traj, 0); lq.q3 = L(u_traj, 0); lq.q1_bs = lq.q2_bs = lq.q3_bs = ts;
             if (alltime) { lq.s3 = dt; lq.ea = L(vhat_T, 0); lq.eb = L(v_traj, 0); lq.ea_bs = lq.eb_bs = ts; }
-            femfct_enqueue_load(ctx, lq, ctx->d_trRhs2, batch);
-            int r = femfct_enqueue_species_solve(ctx, 13, ctx->d_trMat, 0, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget, dt * Dv);
-            if (r != FEMFCT_OK) return r;
-            // then p by FCT (helpers.py:690-697): N = gamma*M - 2*gamma*M_uv, rhs = -2*gamma*u_n*v_n*q_n
+            // N = gamma*M - 2*gamma*M_uv of the p step below (helpers.py:690-692) needs the states only: one launch for the three
             WMassSpec wn_;
             wn_.alpha = gam; wn_.beta = -2.0 * gam; wn_.f1 = L(u_traj, 0); wn_.f2 = L(v_traj, 0); wn_.f1_bs = wn_.f2_bs = ts;
-            femfct_enqueue_weighted_mass(ctx, wn_, ctx->d_trN, batch);
+            FormGroup fg(ctx);
+            fg.weighted_mass(wq, ctx->d_trMat, batch);
+            fg.load(lq, ctx->d_trRhs2, batch);
+            fg.weighted_mass(wn_, ctx->d_trN, batch);
+            int r = fg.launch();
+            if (r != FEMFCT_OK) return r;
+            r = femfct_enqueue_species_solve(ctx, 13, ctx->d_trMat, 0, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget, dt * Dv);
+            if (r != FEMFCT_OK) return r;
+            // then p by FCT (helpers.py:690-697): N = gamma*M - 2*gamma*M_uv (above), rhs = -2*gamma*u_n*v_n*q_n
             LoadSpec lp;
             lp.s1 = 1.0; lp.k2 = -2.0 * gam; lp.q1 = L(u_traj, 0); lp.q2 = L(v_traj, 0); lp.q3 = L(q_traj, 0);
             lp.q1_bs = lp.q2_bs = lp.q3_bs = ts;
@@ -484,21 +492,23 @@ int femfct_chtxs_adjoint(femfct_ctx* ctx, const double* u_traj, const double* v_
                        key_bits(ctx->kry_tol), key_bits((int32_t)femfct_species_cheb(ctx, 15)));
         return femfct_run_graph_reps(ctx, key, reps, -1, [&]() {
             // Mat_p = Dm*Ad - chi*Aa'(u_n, v_n)  (helpers.py:1499-1503)
-            femfct_enqueue_chtxs_matrix(ctx, 1, L(u_traj, 0), ts, L(v_traj, 0), ts, Dm, chi, eta, ctx->d_trA, batch);
             LoadSpec lp;  // assemble(c_n*q_{n+1}/r*w*dx) [+ uhat_n - u_n]  (helpers.py:1505-1507)
             lp.s1 = 1.0 / rescaling; lp.k2 = 1.0; lp.q1 = L(c_traj, 0); lp.q2 = L(q_traj, 1); lp.q1_bs = lp.q2_bs = ts;
             if (alltime) { lp.s2 = 1.0; lp.da = L(uhat, 0); lp.db = L(u_traj, 0); lp.da_bs = lp.db_bs = ts; }
-            femfct_enqueue_load(ctx, lp, ctx->d_trRhs, batch);
-            int r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, make_ref(ctx->d_trRhs), n, L(p_traj, 1), ts, dt,
+            FormGroup fg(ctx);
+            fg.chtxs_matrix(1, L(u_traj, 0), ts, L(v_traj, 0), ts, Dm, chi, eta, ctx->d_trA, batch);
+            fg.load(lp, ctx->d_trRhs, batch);
+            int r = fg.launch();
+            if (r != FEMFCT_OK) return r;
+            r = femfct_enqueue_step_ref(ctx, ctx->d_trA, nullptr, 0, make_ref(ctx->d_trRhs), n, L(p_traj, 1), ts, dt,
                                             L(p_traj, 0), ts, batch, budget);
             if (r != FEMFCT_OK) return r;
             // rhs_q = assemble(chi*u_n*exp(-eta*u_n)*dot(grad(p_n),grad(w))*dx) [+ vhat_n - v_n]  (helpers.py:1531-1534)
             VecRef none = make_ref(nullptr);
+            // ... and M@q_{n+1} + dt*rhs_q (helpers.py:1538) in the same pass
             femfct_enqueue_chtxs_rhs_q(ctx, L(u_traj, 0), ts, L(p_traj, 0), ts, chi, eta, alltime ? L(vhat, 0) : none, ts,
-                                       alltime ? L(v_traj, 0) : none, ts, ctx->d_trTmp, batch);
-            LoadSpec lq;  // M@q_{n+1} + dt*rhs_q  (helpers.py:1538)
-            lq.s0 = 1.0; lq.mx = L(q_traj, 1); lq.mx_bs = ts; lq.s2 = dt; lq.da = make_ref(ctx->d_trTmp); lq.da_bs = n;
-            femfct_enqueue_load(ctx, lq, ctx->d_trRhs2, batch);
+                                       alltime ? L(v_traj, 0) : none, ts, ctx->d_trRhs2, batch, L(q_traj, 1), ts, 1.0, dt);
+            femfct_request_fused_end(ctx, -1, true);
             r = femfct_enqueue_species_solve(ctx, 15, ctx->d_trBase, 1, ctx->d_trRhs2, L(q_traj, 1), ts, L(q_traj, 0), ts, batch, kbudget, dt * Df);
             if (r != FEMFCT_OK) return r;
             return femfct_enqueue_step_end(ctx, -1, batch, true);

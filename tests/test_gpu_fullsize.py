@@ -565,7 +565,8 @@ def test_mimura_named_grid_129x129_forward(hp, monkeypatch):
     finally:
         S.close()
     _report("Mimura-named grid 129^2, 300 steps (T = 30)", u=eu, v=ev)
-    assert eu < TOL and ev < TOL
+    assert eu < TOL and ev < TOL          # the north-star bar
+    assert max(eu, ev) < 1e-10            # what this path delivers (measured 1e-13..1e-12): a regression shows long before 1e-6
 
 
 def test_mimura_named_grid_129x129_alltime_adjoint(hp, monkeypatch):

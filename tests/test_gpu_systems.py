@@ -211,6 +211,60 @@ def test_species_chebyshev_matches_bicgstab(hp):
         S.close()
 
 
+@pytest.mark.parametrize("batch", [1, 3])
+def test_form_groups_and_fused_step_end_are_bitwise_neutral(hp, monkeypatch, batch):
+    """Two launch-count savers of the systems' time steps must not change a bit or a log entry: (i) FEMFCT_FORM_GROUPS --
+    the quadrature forms of a step that depend on earlier levels only share one launch (k_forms2 / k_forms3), and the
+    chemotaxis q right-hand side M q_{n+1} + dt rhs_q is formed in the pass that evaluates rhs_q; (ii) FEMFCT_FUSE_END --
+    the one-launch species solve logs the step and moves the time level itself when it is the step's last operation.
+    Schnakenberg forward + all-time adjoint, chemotaxis forward + all-time adjoint, 60 steps (two graphs of 50 / 10 steps),
+    states, adjoints, FCT-step log and species-solve log."""
+    systems = importlib.import_module("fem-fct-pdeco_amd.systems")
+    V = hp.SquareMeshP1(0.0, 1.0, 40)
+    n, Nt, dt = V.nodes, 60, 5e-4
+    tl = (Nt + 1) * n
+    outs = []
+    for groups, fuse_end in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("FEMFCT_FORM_GROUPS", groups)
+        monkeypatch.setenv("FEMFCT_FUSE_END", fuse_end)
+        rng = np.random.default_rng(23)
+        S = systems.PDESystems(V, order=hp.ORDER_VERTEX)
+        ctx = S.ctx
+        try:
+            def traj(x0):
+                a = np.zeros((batch, tl))
+                a[:, :n] = x0
+                return ctx.array(a.ravel())
+            par, wind = systems._schnak_par()
+            Aw, AwT = S.convection(wind, "schnak")
+            u0, v0 = hp.schnak_sys_IC(0, 1, 0.025, n, np.arange(n))
+            c = ctx.array(0.1 + 0.01 * rng.random((batch, n)).ravel())
+            u, v, p, q = traj(u0), traj(v0), traj(0 * u0), traj(0 * u0)
+            ctx.schnak_forward(Aw, c, u, v, Nt, dt, par, 1.0, batch=batch)
+            logs = [ctx.traj_info(Nt, batch), ctx.traj_krylov_info(Nt, batch)]
+            uh, vh = ctx.array(rng.random(batch * tl)), ctx.array(rng.random(batch * tl))
+            ctx.schnak_adjoint(AwT, u, v, uh, vh, p, q, Nt, dt, par, batch=batch, alltime=True)
+            logs += [ctx.traj_info(Nt, batch), ctx.traj_krylov_info(Nt, batch)]
+            cpar = systems._chtxs_par()
+            cc = ctx.array(20 * rng.random(batch * tl))
+            uc0 = 1.5 + 0.1 * (0.5 - rng.random(n))
+            uc, vc, pc, qc = traj(uc0), traj(uc0), traj(0 * uc0), traj(0 * uc0)
+            ctx.chtxs_forward(cc, uc, vc, Nt, dt, cpar, 0.1, batch=batch)
+            logs += [ctx.traj_info(Nt, batch), ctx.traj_krylov_info(Nt, batch)]
+            ctx.chtxs_adjoint(uc, vc, uh, vh, pc, qc, cc, Nt, dt, cpar, 0.1, alltime=True, batch=batch)
+            logs += [ctx.traj_info(Nt, batch), ctx.traj_krylov_info(Nt, batch)]
+            outs.append(([x.download() for x in (u, v, p, q, uc, vc, pc, qc)], logs))
+        finally:
+            S.close()
+    for arrs, logs in outs[1:]:
+        for a, b in zip(arrs, outs[0][0]):
+            assert np.isfinite(a).all() and np.array_equal(a, b)
+        for la, lb in zip(logs, outs[0][1]):
+            for k in ("flags", "solver_iters", "solver_resid"):
+                assert np.array_equal(la[k], lb[k]), k
+    assert outs[0][0][2].any() and outs[0][0][6].any()
+
+
 def test_mimura_named_config_forward_synthetic(hp, monkeypatch):
     """The 'Mimura-Tsujikawa' scripts at HEAD (chemotaxis_mimura_FCT.py:25-44, mimura_data_helpers.py:82-100) run
     the same chemotaxis operators with delta = 2, Dm = Df = 0.05, chi = 0.125, beta = 0.5 on [0,10]^2: the device
