@@ -236,7 +236,7 @@ class StubProblem:
 # UnitSquare 41 x 41 mesh, dt = 5e-4, 200 forward + 200 adjoint FCT steps, device-resident sweeps
 #   helpers.py:511-698 (solve_schnak_system / solve_adjoint_schnak_system), :1250-1581 (chemotaxis)
 # ---------------------------------------------------------------------------------------------
-def bench_systems(hp, batches=(1, 20), oracle=True, reps=3):
+def bench_systems(hp, batches=(1, 20), oracle=True, reps=3, pgd=True):
     """Per system: forward + adjoint timesteps/s with everything resident in HBM; `parity` of that very run against the
     CPU oracle on the same inputs (relative l2, tolerance 1e-6); the oracle's own 1-core rate on those inputs as
     `cpu_baseline`; the same sweeps with B trajectories per launch (the Armijo trials of helpers.py:1583-1713)."""
@@ -339,6 +339,32 @@ def bench_systems(hp, batches=(1, 20), oracle=True, reps=3):
             for a in ([u, v, p, q, c1] + ([uhT, vhT] if sch else [call, uh, vh])):
                 a.free()
         out[name] = entry
+    if pgd:
+        # whole PGD iterations of the refactored drivers (Schnak_FCT_PDECO_refactored.py:160-262,
+        # chemotaxis_FCT_PDECO_AT_refactored.py:160-270): all Armijo trials of an iteration as one batch vs one by one
+        pdeco = importlib.import_module("fem-fct-pdeco_amd.pdeco")
+        for name, problem, ic, ctrue in (("schnakenberg", "schnak", (u0s, v0s), 0.1), ("chemotaxis", "chtxs", (u0c, v0c), 10.0)):
+            optim = pdeco.DEFAULTS[problem]["optim"]
+            with pdeco.SystemPDECO(problem, V, Nt, dt) as P:      # targets: the build's own forward solve at a constant control
+                c = P._up(np.full(tl, ctrue))
+                us = [P._up(np.concatenate([x0, np.zeros(Nt * n)])) for x0 in ic]
+                P._state(c, us[0], us[1], P._zeros(n), 1)
+                full = [P._down(x) for x in us]
+            tg = [x if optim == "alltime" else x[Nt * n:] for x in full]
+            rec = {}
+            for spec in (True, False):
+                with pdeco.SystemPDECO(problem, V, Nt, dt, max_iter_GD=3, tol=0.0) as P:
+                    P.run(ic, tg, speculative=spec)               # first run: graph captures, sweep budgets settle
+                    P.ctx.synchronize()
+                    t0 = time.perf_counter()
+                    r = P.run(ic, tg, speculative=spec)
+                    el = time.perf_counter() - t0
+                rec["speculative" if spec else "sequential"] = {"ms_per_pgd_iteration": 1e3 * (r["wall"][-1] - r["wall0"]) / max(r["it"], 1),
+                                                                "ms_whole_run_incl_setup_and_initial_solves": 1e3 * el,
+                                                                "armijo_trials": [int(k) for k in r["armijo_its"]],
+                                                                "cost": [float(r["cost"][0]), float(r["cost"][-1])]}
+            rec["max_iter_armijo"] = int(pdeco.DEFAULTS[problem]["max_iter_armijo"])
+            out[name]["pgd"] = rec
     return out
 
 
@@ -630,6 +656,9 @@ def main():
         # speculative = all 10 Armijo trial steps as one batch of independent trajectories
         pg = {}
         for spec in (True, False):
+            # one untimed iteration first: the graphs of this batch size are captured and its sweep budgets settle
+            solvers.pgd_solidbody_finaltime(prob, to_dev(u0), to_dev(uhat), np.ones(tl), 1.0, 0.0, 5.0, 1, speculative=spec)
+            prob.ctx.synchronize()
             t0 = time.perf_counter()
             _, _, _, hist = solvers.pgd_solidbody_finaltime(prob, to_dev(u0), to_dev(uhat), np.ones(tl), 1.0, 0.0, 5.0,
                                                             args.pgd_iters, speculative=spec)

@@ -13,6 +13,8 @@ agree to the solver tolerance) -- the lever that fills the GPU on these small me
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 from . import _lib
@@ -203,7 +205,9 @@ class SystemPDECO:
         it_backup = 0
         # armijo_margin[it][k]: distance of trial k's Armijo test from its threshold relative to the cost,
         # (J_trial - J_k + gam/s ||c_inc - c||^2_Q) / |J_k| (> 0: rejected), for the trials the sequential search looks at
-        hist = dict(cost=[cost_old], armijo_its=[], stop_crit=[], armijo_margin=[])
+        # wall[it]: host clock after iteration it's cost evaluation (a read-back: the device has finished the iteration);
+        # wall0: after the initial state + adjoint + cost -- so (wall[-1] - wall0) / it is the time of an iteration proper
+        hist = dict(cost=[cost_old], armijo_its=[], stop_crit=[], armijo_margin=[], wall=[], wall0=time.perf_counter())
         svals = [P["s0"] / 2 ** k for k in range(K)]
         while (stop_crit >= P["tol"] or fail_pass or it < P["min_iters"]) and it < P["max_iter_GD"]:
             self._descent(c, u, p, q, d)
@@ -266,6 +270,7 @@ class SystemPDECO:
             hist["cost"].append(cost_new)
             hist["armijo_its"].append(iters)
             hist["stop_crit"].append(stop_crit)
+            hist["wall"].append(time.perf_counter())
             if callback is not None:
                 callback(it, cost_new, iters, stop_crit)
             it += 1
