@@ -74,6 +74,7 @@ struct femfct_ctx {
     // the batch straddles the wrap (host SIGSEGV inside librocprofiler-sdk.so; DESIGN.md section 9,
     // tools/graph_intercept_probe.hip reproduces it without this library).  FEMFCT_PROFILER_GRAPHS=1 overrides.
     bool graphs_blocked = false;
+    int graph_captures = 0;            // (FEMFCT_DEBUG: graphs captured + instantiated so far)
     bool profiler_graphs_ok = false;   // FEMFCT_PROFILER_GRAPHS=1
     int32_t steps_per_graph = 50;   // time steps captured per hipGraph in the trajectory drivers (only the last one moves the counters)
     bool use_strips = true;     // strip-fused multi-sweep kernels when the bandwidth allows
@@ -327,6 +328,7 @@ int femfct_run_graph(femfct_ctx* ctx, const femfct_ctx::GraphKey& key, F&& enque
             return enqueue();
         }
         if (ctx->graphs.size() > 64) femfct_drop_graphs(ctx);
+        ++ctx->graph_captures;
         hipGraph_t graph = nullptr;
         HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         int rc = enqueue();

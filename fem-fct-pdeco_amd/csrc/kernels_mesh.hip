@@ -14,8 +14,9 @@
 // and trajectory: A once for the build and once for du/dt, the forward half of D out and in, u_n / rhs in, u_{n+1} out.
 //
 // Layout.  A thread owns a 2 x 2 block of nodes (21 x 21 = 441 threads at 41^2).  In-block neighbours are the thread's
-// own registers; values on the block's rim are published in an LDS image (pitch N + 1 with one shared pad column, pad
-// rows above and below: nodes outside the mesh read 0) and the 2 BX + 2 BY + 2 rim values of the neighbouring blocks are
+// own registers; values on the block's rim are published in an LDS image (pad columns and pad rows around the mesh:
+// nodes outside it read 0; on the 41 x 41 config mesh the columns are stored de-interleaved, even ones then odd ones, so
+// that a wave's accesses are unit-stride -- see xo) and the 2 BX + 2 BY + 2 rim values of the neighbouring blocks are
 // read back after the barrier.  Two images alternate, so a sweep needs one barrier.  Blocks that do not touch the mesh
 // boundary are dealt to the first waves, the boundary ring to the last ones: the interior waves run code without
 // existence masks, with constant mass-matrix weights.
@@ -92,12 +93,29 @@ __device__ __forceinline__ double zsel(bool keep, double v) {
     return keep ? v : 0.0;
 }
 
+// LDS image of a nodal field: rows -1 .. N (zero pad rows), columns -1 .. N.
+// DEINT (2 x 2 blocks on the config mesh, N a compile-time constant): the columns are stored DE-INTERLEAVED -- column x at (u >> 1) + (u & 1) * half, u = x + 1, half = (N + 3) / 2 --
+// so that the 64 threads of a wave, whose blocks are two columns apart, touch consecutive doubles with every access
+// (interleaved, their 16-byte stride uses every other LDS bank pair: two-way conflicts on each of the ~14 reads and
+// writes a sweep makes).  Relative to the slot of column ix0 - 1 the thread's columns ix0 - 1 .. ix0 + 2 are at
+// 0, half, 1, half + 1 (immediates).  The other instantiations keep the plain row, pitch N + 1 with one shared pad
+// column: 3 x 3 blocks are conflict-free as they are (stride 24 bytes), and with N at run time `half` would cost the
+// 2 x 2 variant with a non-flux matrix the registers it does not have.
+template <bool DEINT>
+__host__ __device__ constexpr int mesh_img_doubles(int NMAX) {
+    return DEINT ? (NMAX + 2) * (2 * ((NMAX + 3) / 2)) : (NMAX + 2) * (NMAX + 1) + 1;
+}
+template <bool DEINT>
+__device__ __forceinline__ int xo(int cc, int half) {
+    return DEINT ? ((cc + 1) >> 1) + (((cc + 1) & 1) ? half : 0) : cc;
+}
+
 // value of `val` at node (r + DY, c + DX): the thread's own register inside the block, else the image
 template <int BX, int BY, int DX, int DY>
-__device__ __forceinline__ double nb_get(const double (&val)[BY][BX], double* const (&rowp)[BY + 2], int img, int r, int c) {
+__device__ __forceinline__ double nb_get(const double (&val)[BY][BX], double* const (&rowp)[BY + 2], int img, int r, int c, int half) {
     const int rr = r + DY, cc = c + DX;
     if (rr >= 0 && rr < BY && cc >= 0 && cc < BX) return val[rr][cc];
-    return rowp[rr + 1][img + cc];
+    return half ? rowp[rr + 1][img + xo<true>(cc, half)] : rowp[rr + 1][img + cc];      // (half: 0 = plain rows; a constant at every call)
 }
 
 // publish `val` at the nodes that a neighbouring block reads with nb_get<DX, DY>
@@ -130,12 +148,13 @@ __device__ __forceinline__ void publish_rim(const double (&val)[BY][BX], int img
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ double lds_read(const double* p) { return *(volatile lds_double*)p; }
 template <int BX, int BY>
-__device__ __forceinline__ void gather_halo(double (&v)[BY + 2][BX + 2], double* const (&rowp)[BY + 2], int img) {
-    MS_UNROLL for (int c = -1; c < BX; ++c) v[0][c + 1] = lds_read(&rowp[0][img + c]);
-    MS_UNROLL for (int c = 0; c <= BX; ++c) v[BY + 1][c + 1] = lds_read(&rowp[BY + 1][img + c]);
+__device__ __forceinline__ void gather_halo(double (&v)[BY + 2][BX + 2], double* const (&rowp)[BY + 2], int img, int half) {
+    auto X = [&](int cc) { return half ? xo<true>(cc, half) : cc; };
+    MS_UNROLL for (int c = -1; c < BX; ++c) v[0][c + 1] = lds_read(&rowp[0][img + X(c)]);
+    MS_UNROLL for (int c = 0; c <= BX; ++c) v[BY + 1][c + 1] = lds_read(&rowp[BY + 1][img + X(c)]);
     MS_UNROLL for (int r = 0; r < BY; ++r) {
-        v[r + 1][0] = lds_read(&rowp[r + 1][img - 1]);
-        v[r + 1][BX + 1] = lds_read(&rowp[r + 1][img + BX]);
+        v[r + 1][0] = lds_read(&rowp[r + 1][img + X(-1)]);
+        v[r + 1][BX + 1] = lds_read(&rowp[r + 1][img + X(BX)]);
     }
 }
 
@@ -181,14 +200,17 @@ __device__ __forceinline__ void reduce4(double& a, double& b, double& c, double&
 template <int BX, int BY, int NMAX, int NT, int NFIX, bool HASNM, bool INTERIOR>
 __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* lds, double* red, int* flg, int bx, int by,
                                                int bz, int ord) {
-    constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;      // doubles per image
+    constexpr bool DEINT = BX == 2 && NFIX != 0;      // de-interleaved image columns (see xo)
+    constexpr int IMG = mesh_img_doubles<DEINT>(NMAX);      // doubles per image
     constexpr int NW = NT / WAVE;
     // NFIX: the config mesh (41 nodes per side) gets its own instantiation: every LDS / HBM row offset is then an immediate
-    const int N = NFIX ? NFIX : a.N, n = NFIX ? NFIX * NFIX : a.n, P = N + 1;
+    const int N = NFIX ? NFIX : a.N, n = NFIX ? NFIX * NFIX : a.n;
+    constexpr int half = DEINT ? (NFIX + 3) / 2 : 0;
+    const int P = DEINT ? 2 * half : N + 1;
     const int ix0 = bx * BX, iy0 = by * BY;
     const double dt = a.dt;
-    double* rowp[BY + 2];
-    MS_UNROLL for (int r = -1; r <= BY; ++r) rowp[r + 1] = lds + 1 + (iy0 + r + 1) * P + ix0;
+    double* rowp[BY + 2];      // rowp[r + 1][img + xo(c)]: node (r, c) of the block; DEINT: based at column ix0 - 1
+    MS_UNROLL for (int r = -1; r <= BY; ++r) rowp[r + 1] = DEINT ? lds + (iy0 + r + 1) * P + bx : lds + 1 + (iy0 + r + 1) * P + ix0;
     bool colok[BX], rowok[BY];
     MS_UNROLL for (int c = 0; c < BX; ++c) colok[c] = INTERIOR || (ix0 + c < N);
     MS_UNROLL for (int r = 0; r < BY; ++r) rowok[r] = INTERIOR || (iy0 + r < N);
@@ -203,7 +225,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     auto gidx = [&](int r, int c) { return ALLV ? gi0 + r * N + c : (valid(r, c) ? gi0 + r * N + c : 0); };   // safe to load from
     double* const trash = reinterpret_cast<double*>(flg + 4);
     auto dst = [&](int r, int c, int img) -> double* {
-        double* p = &rowp[r + 1][img + c];
+        double* p = &rowp[r + 1][img + xo<DEINT>(c, half)];
         return ALLV ? p : (valid(r, c) ? p : trash);
     };
     // interior nodes: M_L = h^2, m_ii = h^2 / 2, m_ij = h^2 / 12 (six triangles around the node)
@@ -257,9 +279,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             __syncthreads();
             MS_UNROLL for (int r = 0; r < BY; ++r)
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
-                    const double at = p == 0 ? nb_get<BX, BY, 1, 0>(ao, rowp, 0, r, c)
-                                    : p == 1 ? nb_get<BX, BY, 1, 1>(ao, rowp, 0, r, c)
-                                             : nb_get<BX, BY, 0, 1>(ao, rowp, 0, r, c);
+                    const double at = p == 0 ? nb_get<BX, BY, 1, 0>(ao, rowp, 0, r, c, half)
+                                    : p == 1 ? nb_get<BX, BY, 1, 1>(ao, rowp, 0, r, c, half)
+                                             : nb_get<BX, BY, 0, 1>(ao, rowp, 0, r, c, half);
                     ds[r][c] = fmax(0.0, fmax(as[r][c], at));            // d_ij = max(0, a_ij, a_ji), once per edge
                     (Dh + (ALLV || valid(r, c) ? (int64_t)s * n : 0))[gidx(r, c)] = ds[r][c];
                     dsum[r][c] += ds[r][c];
@@ -272,9 +294,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             __syncthreads();
             MS_UNROLL for (int r = 0; r < BY; ++r)
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
-                    const double dbk = p == 0 ? nb_get<BX, BY, -1, 0>(ds, rowp, IMG, r, c)
-                                     : p == 1 ? nb_get<BX, BY, -1, -1>(ds, rowp, IMG, r, c)
-                                              : nb_get<BX, BY, 0, -1>(ds, rowp, IMG, r, c);
+                    const double dbk = p == 0 ? nb_get<BX, BY, -1, 0>(ds, rowp, IMG, r, c, half)
+                                     : p == 1 ? nb_get<BX, BY, -1, -1>(ds, rowp, IMG, r, c, half)
+                                              : nb_get<BX, BY, 0, -1>(ds, rowp, IMG, r, c, half);
                     dsum[r][c] += dbk;
                     double lb = dt * (ao[r][c] - dbk);
                     if (HASNM) {
@@ -301,7 +323,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 a0v[c] = Ab[i]; uv[c] = un[i];
                 rb[c] = 0.0; nmv[c] = 0.0; mlv0[c] = hh;
                 if (!INTERIOR) mlv0[c] = a.ml[i];
-                dsv[c] = LEAN ? lds_read(&rowp[r + 1][IMG + c]) : dsum[r][c];
+                dsv[c] = LEAN ? lds_read(&rowp[r + 1][IMG + xo<DEINT>(c, half)]) : dsum[r][c];
             }
             MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = rhs[gidx(r, c)];
             if (HASNM) {
@@ -357,7 +379,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         // last row the top halo row.  Rows descending: mirrored.
         auto stage = [&](const int img_in, const int r, auto revtag) {
             constexpr bool rev = decltype(revtag)::value;
-            auto ld = [&](int hr, int hc) { v[hr][hc] = lds_read(&rowp[hr][img_in + hc - 1]); };    // v[hr][hc] = node (hr - 1, hc - 1)
+            auto ld = [&](int hr, int hc) { v[hr][hc] = lds_read(&rowp[hr][img_in + xo<DEINT>(hc - 1, half)]); };    // v[hr][hc] = node (hr - 1, hc - 1)
             if (!rev) {
                 ld(r + 1, 0);
                 if (r + 2 <= BY) ld(r + 2, BX + 1);
@@ -396,7 +418,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 const int r = rev ? BY - 1 - t : t;
                 if (t > 0) stage(img_in, r, revtag);
                 double bpv[BX];            // LEAN: the row's b / l_ii, requested with its halo values
-                MS_UNROLL for (int c = 0; c < BX; ++c) bpv[c] = LEAN ? lds_read(&rowp[r + 1][2 * IMG + c]) : bp[r][c];
+                MS_UNROLL for (int c = 0; c < BX; ++c) bpv[c] = LEAN ? lds_read(&rowp[r + 1][2 * IMG + xo<DEINT>(c, half)]) : bp[r][c];
                 MS_UNROLL for (int u = 0; u < BX; ++u) {
                     const int c = rev ? BX - 1 - u : u;
                     auto nb = [&](int dy, int dx) -> double { return nbv<BX, BY>(x, v, r + dy, c + dx); };
@@ -506,7 +528,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         auto cheb = [&](double (&ycur)[BY][BX], double (&yold)[BY][BX], const int it) {
             publish_rim<BX, BY>(ycur, q ? IMG : 0, dst);
             __syncthreads();
-            gather_halo<BX, BY>(v, rowp, q ? IMG : 0);
+            gather_halo<BX, BY>(v, rowp, q ? IMG : 0, half);
             const double om = a.om[(it - 1) % 20];
             MS_UNROLL for (int r = 0; r < BY; ++r)
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
@@ -545,7 +567,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         {
             // forward fluxes first (u_L, du/dt of the E, NE, N neighbours), then the bounds (all six u_L): the register
             // budget of 3 waves per SIMD holds one of the two halo sets at a time
-            gather_halo<BX, BY>(v, rowp, 2 * IMG);
+            gather_halo<BX, BY>(v, rowp, 2 * IMG, half);
             {
                 const double mq = (0.5 * hh) / 12.0;
                 const int qi = q ? IMG : 0;
@@ -555,9 +577,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                         int pc = 0;
                         if (!INTERIOR) pc = mass_edge_counts(ix0 + c, iy0 + r, N - 1);
                         MS_UNROLL for (int s = 1; s <= 3; ++s) {
-                            const double duj = s == 1 ? nb_get<BX, BY, 1, 0>(ym, rowp, qi, r, c)
-                                             : s == 2 ? nb_get<BX, BY, 1, 1>(ym, rowp, qi, r, c)
-                                                      : nb_get<BX, BY, 0, 1>(ym, rowp, qi, r, c);
+                            const double duj = s == 1 ? nb_get<BX, BY, 1, 0>(ym, rowp, qi, r, c, half)
+                                             : s == 2 ? nb_get<BX, BY, 1, 1>(ym, rowp, qi, r, c, half)
+                                                      : nb_get<BX, BY, 0, 1>(ym, rowp, qi, r, c, half);
                             const double mij = INTERIOR ? 2.0 * mq : (double)((pc >> (2 * (s - 1))) & 3) * mq;
                             const double dij = vz(r, c, (Dh + (int64_t)s * n)[i]);
                             const double fs = mij * (ym[r][c] - duj) + dij * (x[r][c] - nbv<BX, BY>(x, v, r + ms_dy(s), c + ms_dx(s)));
@@ -598,9 +620,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         MS_UNROLL for (int r = 0; r < BY; ++r)
             MS_UNROLL for (int c = 0; c < BX; ++c) {
                 // backward slots: f_ij = -f_ji, the bits the neighbour computed
-                const double fw = -nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c);
-                const double fsw = -nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c);
-                const double fs = -nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c);
+                const double fw = -nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c, half);
+                const double fsw = -nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c, half);
+                const double fs = -nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c, half);
                 double pp = 0.0, pm = 0.0;
                 MS_UNROLL for (int s = 0; s < 3; ++s) { pp += fmax(ff[s][r][c], 0.0); pm += fmin(ff[s][r][c], 0.0); }
                 pp += fmax(fw, 0.0); pm += fmin(fw, 0.0);
@@ -621,12 +643,12 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             MS_UNROLL for (int c = 0; c < BX; ++c) {
                 double acc = 0.0;
                 MS_UNROLL for (int s = 0; s < 3; ++s) {
-                    const double rpj = s == 0 ? nb_get<BX, BY, 1, 0>(rp, rowp, 0, r, c)
-                                     : s == 1 ? nb_get<BX, BY, 1, 1>(rp, rowp, 0, r, c)
-                                              : nb_get<BX, BY, 0, 1>(rp, rowp, 0, r, c);
-                    const double rmj = s == 0 ? nb_get<BX, BY, 1, 0>(rm, rowp, IMG, r, c)
-                                     : s == 1 ? nb_get<BX, BY, 1, 1>(rm, rowp, IMG, r, c)
-                                              : nb_get<BX, BY, 0, 1>(rm, rowp, IMG, r, c);
+                    const double rpj = s == 0 ? nb_get<BX, BY, 1, 0>(rp, rowp, 0, r, c, half)
+                                     : s == 1 ? nb_get<BX, BY, 1, 1>(rp, rowp, 0, r, c, half)
+                                              : nb_get<BX, BY, 0, 1>(rp, rowp, 0, r, c, half);
+                    const double rmj = s == 0 ? nb_get<BX, BY, 1, 0>(rm, rowp, IMG, r, c, half)
+                                     : s == 1 ? nb_get<BX, BY, 1, 1>(rm, rowp, IMG, r, c, half)
+                                              : nb_get<BX, BY, 0, 1>(rm, rowp, IMG, r, c, half);
                     const double f = ff[s][r][c];
                     const double al = (f > 0.0) ? fmin(rp[r][c], rmj) : fmin(rm[r][c], rpj);
                     ff[s][r][c] = al * f;                 // limited flux of the forward edge
@@ -643,9 +665,9 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         MS_UNROLL for (int r = 0; r < BY; ++r)
             MS_UNROLL for (int c = 0; c < BX; ++c) {
                 double acc = fbar[r][c];
-                acc -= nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c);
-                acc -= nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c);
-                acc -= nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c);
+                acc -= nb_get<BX, BY, -1, 0>(ff[0], rowp, 0, r, c, half);
+                acc -= nb_get<BX, BY, -1, -1>(ff[1], rowp, IMG, r, c, half);
+                acc -= nb_get<BX, BY, 0, -1>(ff[2], rowp, 2 * IMG, r, c, half);
                 (ALLV || valid(r, c) ? out : Dh)[gidx(r, c)] = fma(rml[r][c], acc, x[r][c]);
             }
     }
@@ -672,7 +694,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
 template <int BX, int BY, int NMAX, int NT, int NFIX, bool HASNM>
 __global__ void __launch_bounds__(NT) k_mesh_step(MeshStepArgs a) {
     extern __shared__ double lds[];
-    constexpr int IMG = (NMAX + 2) * (NMAX + 1) + 1;
+    constexpr int IMG = mesh_img_doubles<(BX == 2 && NFIX != 0)>(NMAX);
     double* red = lds + 3 * IMG;                         // 4 * NT / 64 doubles
     int* flg = reinterpret_cast<int*>(red + 4 * (NT / WAVE));   // 4 ints, then one trash double
     const int bz = blockIdx.x, tid = threadIdx.x;
@@ -783,7 +805,7 @@ int femfct_enqueue_mesh_step(femfct_ctx* ctx, MatRef A, const double* Nm, int32_
     femfct_prof_begin(ctx, KC_JACOBI);
 #define MS_LAUNCH(B, NMAX_, NT_, NFIX_, NM_, slot)                                                                       \
     do {                                                                                                                 \
-        constexpr size_t lds = (size_t)(3 * ((NMAX_ + 2) * (NMAX_ + 1) + 1) + 4 * (NT_ / WAVE)) * 8 + 24;                \
+        constexpr size_t lds = (size_t)(3 * mesh_img_doubles<(B == 2 && NFIX_ != 0)>(NMAX_) + 4 * (NT_ / WAVE)) * 8 + 24;                \
         if (nthreads > NT_) return femfct_fail(ctx, FEMFCT_ERR_INVALID, "one-workgroup step: mesh does not fit");        \
         if (!ctx->mesh_step_attr[slot]) {                                                                                \
             HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_mesh_step<B, B, NMAX_, NT_, NFIX_, NM_>,                          \

@@ -1,6 +1,8 @@
 // Shared machinery of the trajectory drivers (traj.hip, traj_systems.hip).
 #pragma once
 
+#include <chrono>
+
 #include "femfct_internal.h"
 #include "device_utils.h"
 #include "forms.h"
@@ -96,8 +98,12 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
         if (meshp && !ctx->kind_mesh_budget.count(kind)) ctx->kind_mesh_budget[kind] = std::min(ctx->max_iters, 96);
         const int budget = meshp ? ctx->kind_mesh_budget[kind] : femfct_round_budget(ctx, ctx->kind_budget[kind]);
         const int kbudget = femfct_round_kry_budget(ctx, ctx->kind_kbudget[kkey]);
+        const bool dbg_t = getenv("FEMFCT_DEBUG_TIMES") != nullptr;
+        auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tt0 = dbg_t ? now() : 0.0;
         int rc = begin();
         if (rc != FEMFCT_OK) return rc;
+        const double tt1 = dbg_t ? now() : 0.0;
         int32_t init[2] = {level0, 0};
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_level, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
         // several identical time steps per captured graph: fewer graph launches, no inter-graph gaps
@@ -106,6 +112,7 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
             rc = step(budget, kbudget, std::min(per_graph, num_steps - k));
             if (rc != FEMFCT_OK) return rc;
         }
+        const double tt2 = dbg_t ? now() : 0.0;
         ctx->log_steps = ctx->log_batch = 0;      // no matching log while the copies are in flight / after a failure
         ctx->h_log.resize((size_t)num_steps * batch);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_log.data(), ctx->d_log, sizeof(StepCtl) * ctx->h_log.size(),
@@ -118,6 +125,11 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
             ctx->h_klog.clear();
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (dbg_t) {
+            const double tt3 = now();
+            if (tt3 - tt0 > atof(getenv("FEMFCT_DEBUG_TIMES")))      // FEMFCT_DEBUG_TIMES=<ms>: report sweeps that take longer
+                fprintf(stderr, "[femfct] sweep kind %d took %.1f ms: begin %.2f, enqueue %.2f, wait %.2f\n", kind, tt3 - tt0, tt1 - tt0, tt2 - tt1, tt3 - tt2);
+        }
         ctx->log_steps = num_steps;
         ctx->log_batch = batch;
         int worst = 0, kworst = 0;
@@ -149,8 +161,8 @@ int femfct_run_sweep(femfct_ctx* ctx, int kind, int32_t num_steps, int32_t batch
             }
         }
         if (getenv("FEMFCT_DEBUG"))
-            fprintf(stderr, "[femfct] sweep kind %d: budget %d (krylov %d) worst %d kworst %d short %d/%d\n", kind, budget,
-                    kbudget, worst, kworst, (int)short_budget, (int)kshort);
+            fprintf(stderr, "[femfct] sweep kind %d: budget %d (krylov %d) worst %d kworst %d short %d/%d, %d graphs captured so far (%zu cached)\n",
+                    kind, budget, kbudget, worst, kworst, (int)short_budget, (int)kshort, ctx->graph_captures, ctx->graphs.size());
         if (!short_budget && !kshort && meshp) {
             if (krylov)
                 ctx->kind_kbudget[kkey] = std::min(ctx->kry_max_iters, cheb ? std::max(8, kworst + 1)
