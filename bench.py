@@ -363,7 +363,11 @@ def bench_systems(hp, batches=(1, 20), oracle=True, reps=3, pgd=True):
                     t0 = time.perf_counter()
                     r = P.run(ic, tg, speculative=spec)
                     el = time.perf_counter() - t0
-                rec["speculative" if spec else "sequential"] = {"ms_per_pgd_iteration": 1e3 * (r["wall"][-1] - r["wall0"]) / max(r["it"], 1),
+                per_it = sorted(b - a for a, b in zip([r["wall0"]] + r["wall"][:-1], r["wall"]))
+                # speculative: every iteration evaluates all trials, so the median iteration is the typical one (an occasional
+                # stalled sweep stays out); sequential: the iterations differ by their trial counts -> mean
+                rec["speculative" if spec else "sequential"] = {"ms_per_pgd_iteration": 1e3 * (per_it[len(per_it) // 2] if spec else sum(per_it) / len(per_it)),
+                                                                "ms_per_pgd_iteration_mean": 1e3 * (r["wall"][-1] - r["wall0"]) / max(r["it"], 1),
                                                                 "ms_whole_run_incl_setup_and_initial_solves": 1e3 * el,
                                                                 "armijo_trials": [int(k) for k in r["armijo_its"]],
                                                                 "cost": [float(r["cost"][0]), float(r["cost"][-1])]}
@@ -668,9 +672,14 @@ def main():
             t0 = time.perf_counter()
             _, _, _, hist = solvers.pgd_solidbody_finaltime(prob, to_dev(u0), to_dev(uhat), np.ones(tl), 1.0, 0.0, 5.0,
                                                             args.pgd_iters, speculative=spec)
-            dt_it = (time.perf_counter() - t0) / len(hist["cost"])
+            # median iteration (each ends with a cost read-back, hist["wall"]): the loop's set-up and an occasional stalled
+            # sweep stay out of it; the mean over the whole call is reported beside it
+            walls = [hist["wall0"]] + hist["wall"]
+            per_it = sorted(b - a for a, b in zip(walls[:-1], walls[1:]))
+            dt_it = per_it[len(per_it) // 2]
             pg["speculative" if spec else "sequential"] = {
-                "s_per_pgd_iteration": dt_it, "armijo_trials": hist["armijo_k"], "cost": hist["cost"][-1],
+                "s_per_pgd_iteration": dt_it, "s_per_pgd_iteration_mean_incl_setup": (time.perf_counter() - t0) / len(hist["cost"]),
+                "armijo_trials": hist["armijo_k"], "cost": hist["cost"][-1],
                 "armijo_margin_min": hist["armijo_margin_min"]}
         pg["cost_rel_diff"] = abs(pg["speculative"]["cost"] - pg["sequential"]["cost"]) / abs(pg["sequential"]["cost"])
         pg["note"] = ("every line search exhausts on this data (slotted disc, reference target of another code version): the "
@@ -695,7 +704,8 @@ def main():
                 t0 = time.perf_counter()
                 _, _, _, h5 = solvers.pgd_solidbody_alltime(p5, g0, uhat5, np.ones(tl5), 1e-3, 0.0, 5.0, 3, max_armijo=6, speculative=spec)
                 mix["speculative" if spec else "sequential"] = {
-                    "s_per_pgd_iteration": (time.perf_counter() - t0) / len(h5["cost"]), "armijo_trials": h5["armijo_k"],
+                    "s_per_pgd_iteration": sorted(b - a for a, b in zip([h5["wall0"]] + h5["wall"][:-1], h5["wall"]))[len(h5["wall"]) // 2],
+                    "s_per_pgd_iteration_mean_incl_setup": (time.perf_counter() - t0) / len(h5["cost"]), "armijo_trials": h5["armijo_k"],
                     "cost": h5["cost"][-1], "armijo_margin_min": h5["armijo_margin_min"]}
             mix["same_decisions"] = mix["speculative"]["armijo_trials"] == mix["sequential"]["armijo_trials"]
             mix["cost_rel_diff"] = abs(mix["speculative"]["cost"] - mix["sequential"]["cost"]) / abs(mix["sequential"]["cost"])

@@ -15,6 +15,8 @@ DoF order, mutate the state array in place *and* return it, like the reference.
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 from . import _lib
@@ -220,7 +222,7 @@ def pgd_solidbody(prob: SolidBodyDrift, u0, uhat, c0, beta, c_lower, c_upper, it
     # armijo_margin: per iteration, for every trial the sequential search looks at, the distance of the Armijo test from
     # its threshold relative to the cost, (J_trial - J_k + gam/s ||c_inc - c||^2_Q) / |J_k|  (> 0: rejected).  A margin of
     # the size of the solver tolerance would mean that two faithful implementations may decide differently.
-    hist = dict(cost=[], armijo_k=[], step=[], rel_change=[], armijo_margin=[])
+    hist = dict(cost=[], armijo_k=[], step=[], rel_change=[], armijo_margin=[], wall=[], wall0=time.perf_counter())
     if alltime:
         u.copy_from(uh, tl - n, dst_off=n, src_off=n)      # uk = np.copy(uhat_all), level 0 = u0
     else:
@@ -264,6 +266,7 @@ def pgd_solidbody(prob: SolidBodyDrift, u0, uhat, c0, beta, c_lower, c_upper, it
                 c_prev.copy_from(cB, tl)
                 u.copy_from(uB, tl)
             hist["cost"].append(J_acc)
+            hist["wall"].append(time.perf_counter())          # (J_acc is a read-back: the iteration's device work is done)
             hist["armijo_margin"].append(margins)
             hist["armijo_k"].append(accepted + 1)
             hist["step"].append(svals[accepted])
