@@ -41,3 +41,20 @@ def test_pmc_traffic_classes_and_split_chebyshev_launch(tmp_path):
     assert abs(b["build_low"] - (2 * 40.0 + 4.0) * kib) < 1e-6
     assert abs(t["one_sweep_bytes_per_launch"]["jacobi"] - (2 * 10.0 + 1.0) * kib) < 1e-6
     assert len(t["source_sha16"]) == 16
+
+
+def test_bench_bytes_model_of_the_bandwidth_regime():
+    """bench.launch_bytes_per_row: what a launch must move per matrix row (the numerator of roofline.frac) under the
+    traffic savers of the bandwidth regime -- operator derived in the kernels, its rotation part from the node positions,
+    D once per edge, the zeros of L neither stored nor loaded."""
+    sys.path.insert(0, ROOT)
+    import bench
+    base = bench.launch_bytes_per_row(fused=True, geom_mass=True)
+    assert base["jacobi"] == 80 and base["build_low"] == 200 and base["dudt_rhs"] == 96 and base["cheb"] == 32
+    inl = bench.launch_bytes_per_row(fused=True, geom_mass=True, inline_ops=True, half_d=True, l_nonzero=0.5)
+    rot = bench.launch_bytes_per_row(fused=True, geom_mass=True, inline_ops=True, half_d=True, l_nonzero=0.5, rot_geom=True)
+    assert inl["build_low"] - rot["build_low"] == 56 and inl["dudt_rhs"] - rot["dudt_rhs"] == 56      # Arot: 7 doubles per row
+    assert rot["dudt_rhs"] == 48 and abs(rot["build_low"] - 97) < 1e-9
+    assert abs(inl["jacobi"] - (8 + 24 + 24 + 1)) < 1e-9 and inl["flux"] == 56
+    # without the inline operator the rotation flag has nothing to act on
+    assert bench.launch_bytes_per_row(fused=True, geom_mass=True, rot_geom=True) == base
