@@ -15,6 +15,7 @@ EX = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
     ("c3_c4_systems_pdeco.py", ["nonlinear", "--iters", "1"], "PGD iterations in"),
     ("c3_c4_systems_pdeco.py", ["schnak", "--iters", "1", "--named-c3"], "schnak (alltime): 1 PGD iterations in"),
     ("c5_beta_sweep.py", ["--iters", "1"], "beta = "),
+    ("c5_beta_trial_batch.py", ["--steps", "10", "--betas", "3", "--trials", "4"], "accepted trial"),
 ])
 def test_example_runs(script, args, needle):
     out = subprocess.run([sys.executable, os.path.join(EX, script)] + args, capture_output=True, text=True, timeout=300,
