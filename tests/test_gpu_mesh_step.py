@@ -40,6 +40,7 @@ def _inputs(hp, nc, Nt, B, seed):
 
 def _run(hp, solvers, monkeypatch, mesh_step, nc, Nt, B, eps, seed=7, graphs=True, large_from=None):
     monkeypatch.setenv("FEMFCT_MESH_STEP", "1" if mesh_step else "0")
+    monkeypatch.setenv("FEMFCT_MESH_STEP_BATCH", "1")       # (the default; a knob-matrix run may have moved it)
     if large_from is None:
         monkeypatch.delenv("FEMFCT_MESH_STEP_BATCH_LARGE", raising=False)
     else:
@@ -126,6 +127,7 @@ def test_mesh_step_batched_equals_single_and_graphs_are_neutral(hp, solvers, mon
     _, ue, pe, _ = _run(hp, solvers, monkeypatch, True, nc, Nt, B, 0.0, seed=3, graphs=False)
     assert np.array_equal(ub, ue) and np.array_equal(pb, pe)             # captured graphs vs kernel-by-kernel
     monkeypatch.setenv("FEMFCT_MESH_STEP", "1")
+    monkeypatch.setenv("FEMFCT_MESH_STEP_BATCH", "1")
     mesh, n, tl, u0, c, src = _inputs(hp, nc, Nt, B, 3)
     prob = solvers.SolidBodyDrift(mesh, Nt, 1e-3 * 80 / nc, batch=1, order=hp.ORDER_VERTEX)
     try:
@@ -175,6 +177,7 @@ def test_mesh_step_vs_oracle_41x41(hp, solvers, monkeypatch):
     from oracle.assembly import P1Assembler
     from oracle import traj as otraj
     monkeypatch.setenv("FEMFCT_MESH_STEP", "1")
+    monkeypatch.setenv("FEMFCT_MESH_STEP_BATCH", "1")
     nc, Nt, dt, om = 40, 25, 2e-3, np.pi / 40
     omesh = SquareMesh(-1.0, 1.0, nc)
     asm = P1Assembler(omesh)
