@@ -1,7 +1,7 @@
 #!/bin/bash
 # The GPU suite under the tuning-knob settings DESIGN.md section 4 lists, one line per setting with its pass count:
 #   gpurun --timeout 1190 -- 'bash tools/knob_matrix.sh r04 [part]'   ->  gpurun_out/prof/r04_knobs[_part].txt
-# Part d: the default setting only (whole suite).  Parts f1..f5: the settings that switch bandwidth- or batch-regime kernels, the WHOLE suite each (heavy oracle tests
+# Part d: the default setting only (whole suite).  Part x: the settings in $KNOB_SET (whole suite each).  Parts f1..f5: the settings that switch bandwidth- or batch-regime kernels, the WHOLE suite each (heavy oracle tests
 # included: those are the ones that meet the oracle at the config sizes).
 # Parts a, b, c: the other settings, without the heavy full-size oracle tests (PGD loops at 81^2 x 250, 1025^2, Mimura
 # T = 30: ~2 min of CPU oracle per pass); part a also runs the default setting with the whole suite.
@@ -23,7 +23,7 @@ F4=("FEMFCT_TILE4=2" "FEMFCT_MESH_STEP_BATCH=8" "FEMFCT_GEOM_ROT=0")
 F5=("FEMFCT_FORM_GROUPS=0" "FEMFCT_FUSE_END=0" "FEMFCT_MESH_SOLVE=0")
 FULL=0
 case $PART in a) SET=("${A[@]}");; b) SET=("${B[@]}");; c) SET=("${C[@]}");;
-  f1) SET=("${F1[@]}"); FULL=1;; f2) SET=("${F2[@]}"); FULL=1;; f3) SET=("${F3[@]}"); FULL=1;; f4) SET=("${F4[@]}"); FULL=1;; f5) SET=("${F5[@]}"); FULL=1;; d) SET=(); FULL=1;;
+  f1) SET=("${F1[@]}"); FULL=1;; f2) SET=("${F2[@]}"); FULL=1;; f3) SET=("${F3[@]}"); FULL=1;; f4) SET=("${F4[@]}"); FULL=1;; f5) SET=("${F5[@]}"); FULL=1;; d) SET=(); FULL=1;; x) SET=(${KNOB_SET}); FULL=1;;
   *) SET=("${A[@]}" "${B[@]}" "${C[@]}");; esac
 [ $FULL = 1 ] && SKIP=""
 : > $F
