@@ -11,7 +11,8 @@
 // advection_solidbody_FCT_PDECO_alltime.py:43-74) those launches reach 2-27 % of the HBM roofline.  Here B trajectories
 // are B workgroups that never wait for each other: the mesh lives in one CU -- matrix rows in registers, the iterate in
 // registers + an LDS image for the neighbours -- and __syncthreads() is the only synchronisation.  HBM traffic per step
-// and trajectory: A once for the build and once for du/dt, the forward half of D out and in, u_n / rhs in, u_{n+1} out.
+// and trajectory: A once (2 x 2 blocks without a non-flux matrix keep its rows in registers from the build to du/dt; the
+// other variants read it a second time there), the forward half of D out and in, u_n / rhs in, u_{n+1} out.
 //
 // Layout.  A thread owns a 2 x 2 block of nodes (21 x 21 = 441 threads at 41^2).  In-block neighbours are the thread's
 // own registers; values on the block's rim are published in an LDS image (pad columns and pad rows around the mesh:
@@ -248,6 +249,23 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
     constexpr bool LEAN = BX * BY > 4;
     double x[BY][BX], bp[BY][BX], lc[6][BY][BX], ldv[BY][BX];
     double bmax = 0.0, rsmin = INFINITY, ldmax = 0.0;
+    // KEEP (2 x 2 blocks without a non-flux matrix: 146 of the 256 registers a 512-thread workgroup may have): every HBM
+    // operand of the step -- the seven entries of each row of A, u_n, rhs, and on the boundary ring M_L and diag(M) -- is
+    // requested ONCE, here, ahead of the first barrier, and stays in registers: the pair loop, the du/dt phase and the
+    // limiter then wait for no memory round trip (three, two and one of them before).
+    constexpr bool KEEP = !HASNM && BX * BY <= 4;
+    double ak[7][BY][BX], uk[BY][BX], rk[BY][BX], mlk[BY][BX], mdk[BY][BX];
+    if (KEEP) {
+        MS_UNROLL for (int r = 0; r < BY; ++r)
+            MS_UNROLL for (int c = 0; c < BX; ++c) {
+                const int i = gidx(r, c);
+                MS_UNROLL for (int s = 0; s < 7; ++s) ak[s][r][c] = (Ab + (int64_t)s * n)[i];
+                uk[r][c] = un[i];
+                rk[r][c] = rhs[i];
+                mlk[r][c] = hh; mdk[r][c] = 0.5 * hh;
+                if (!INTERIOR) { mlk[r][c] = a.ml[i]; mdk[r][c] = a.Md[i]; }
+            }
+    }
     double nrow[BY][BX];          // HASNM: row sums of the non-flux matrix (for the row-sum diagnostic, with du/dt)
     MS_UNROLL for (int r = 0; r < BY; ++r)
         MS_UNROLL for (int c = 0; c < BX; ++c) nrow[r][c] = 0.0;
@@ -261,7 +279,8 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             MS_UNROLL for (int r = 0; r < BY; ++r)
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
                     // (uniform base + one 32-bit offset per thread: the slot and the node are immediates)
-                    const double t1 = (Ab + (int64_t)s * n)[gidx(r, c)], t2 = (Ab + (int64_t)o * n)[gidx(r, c)];
+                    const double t1 = KEEP ? ak[s][r][c] : (Ab + (int64_t)s * n)[gidx(r, c)],
+                                 t2 = KEEP ? ak[o][r][c] : (Ab + (int64_t)o * n)[gidx(r, c)];
                     as[r][c] = vz(r, c, t1);
                     ao[r][c] = vz(r, c, t2);
                 }
@@ -320,12 +339,12 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
             double a0v[BX], uv[BX], rb[BX], mlv0[BX], nmv[BX], dsv[BX];
             MS_UNROLL for (int c = 0; c < BX; ++c) {
                 const int i = gidx(r, c);
-                a0v[c] = Ab[i]; uv[c] = un[i];
+                a0v[c] = KEEP ? ak[0][r][c] : Ab[i]; uv[c] = KEEP ? uk[r][c] : un[i];
                 rb[c] = 0.0; nmv[c] = 0.0; mlv0[c] = hh;
-                if (!INTERIOR) mlv0[c] = a.ml[i];
+                if (!INTERIOR) mlv0[c] = KEEP ? mlk[r][c] : a.ml[i];
                 dsv[c] = LEAN ? lds_read(&rowp[r + 1][IMG + xo<DEINT>(c, half)]) : dsum[r][c];
             }
-            MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = rhs[gidx(r, c)];
+            MS_UNROLL for (int c = 0; c < BX; ++c) rb[c] = KEEP ? rk[r][c] : rhs[gidx(r, c)];
             if (HASNM) {
                 MS_UNROLL for (int c = 0; c < BX; ++c) nmv[c] = Nm[gidx(r, c)];
             }
@@ -472,14 +491,14 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
                 double ar[7][BX], rd[BX], mdv[BX], nsum[BX];
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
                     const int i = gidx(r, c);
-                    MS_UNROLL for (int s = 0; s < 7; ++s) ar[s][c] = (Ab + (int64_t)s * n)[i];
+                    MS_UNROLL for (int s = 0; s < 7; ++s) ar[s][c] = KEEP ? ak[s][r][c] : (Ab + (int64_t)s * n)[i];
                     rd[c] = 0.0; mdv[c] = 0.5 * hh; nsum[c] = 0.0;
-                    if (!INTERIOR) mdv[c] = a.Md[i];
+                    if (!INTERIOR) mdv[c] = KEEP ? mdk[r][c] : a.Md[i];
                 }
                 if (HASNM) {
                     MS_UNROLL for (int c = 0; c < BX; ++c) nsum[c] = nrow[r][c];
                 }
-                MS_UNROLL for (int c = 0; c < BX; ++c) rd[c] = rhs[gidx(r, c)];
+                MS_UNROLL for (int c = 0; c < BX; ++c) rd[c] = KEEP ? rk[r][c] : rhs[gidx(r, c)];
                 MS_FENCE();
                 MS_UNROLL for (int c = 0; c < BX; ++c) {
                     double acc = ar[0][c] * x[r][c], asum = ar[0][c];
@@ -611,7 +630,7 @@ __device__ __forceinline__ void mesh_step_body(const MeshStepArgs& a, double* ld
         __syncthreads();
         double rp[BY][BX], rm[BY][BX], rml[BY][BX];      // R+, R-, dt / M_L
         MS_UNROLL for (int r = 0; r < BY; ++r)
-            MS_UNROLL for (int c = 0; c < BX; ++c) rml[r][c] = INTERIOR ? dt / hh : a.ml[gidx(r, c)];
+            MS_UNROLL for (int c = 0; c < BX; ++c) rml[r][c] = INTERIOR ? dt / hh : (KEEP ? mlk[r][c] : a.ml[gidx(r, c)]);
         if (!INTERIOR) {
             MS_FENCE();
             MS_UNROLL for (int r = 0; r < BY; ++r)
